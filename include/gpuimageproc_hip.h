@@ -1,0 +1,336 @@
+/*
+ * gpuimageproc_hip.h -- C-ABI of libgpuimageproc_hip.so, the MI355X (gfx950) implementation of the
+ * `gpuimageproc` stereo hot path (debayer -> rectify -> StereoBM -> speckle -> reproject/PointCloud2).
+ *
+ * Drop-in boundary: the reference sits behind the C++ class gpuimageproc::GpuStereoProcessor
+ * (reference include/gpuimageproc/GPUStereoProcessor.h:63-104); every method of that class has one
+ * extern "C" entry point here with the same argument meaning, plain pointers and sizes only.  The
+ * reference throws / asserts; this ABI returns an int status (0 = GIP_OK) and never throws.
+ * A C++ mirror of the class on top of this ABI lives in include/gpuimageproc/GPUStereoProcessor.hpp;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Three layers:
+ *   gipk_*  stateless kernel launchers on DEVICE pointers (batched, stream-ordered)   -- used by tests/bench
+ *   gip_*   handle API mirroring GpuStereoProcessor (slots, two streams, senders)     -- the drop-in
+ *   gip_batch_* device-resident multi-frame pipeline used by the throughput benchmark
+ */
+#ifndef GPUIMAGEPROC_HIP_H
+#define GPUIMAGEPROC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+enum {
+    GIP_OK                  = 0,
+    GIP_ERR_INVALID_ARG     = 1, /* reference: assert()/cv::Exception */
+    GIP_ERR_NOT_INITIALISED = 2, /* reference: assert(model_.initialized()), GPUStereoProcessor.cpp:238,:266,:307 */
+    GIP_ERR_HIP             = 3, /* a hip* call failed; see gip_last_error */
+    GIP_ERR_UNSUPPORTED     = 4,
+    GIP_ERR_NO_DEVICE       = 5,
+    GIP_ERR_EMPTY_SLOT      = 6,
+    GIP_ERR_IO              = 7
+};
+
+/* ------------------------------------------------------------------ buffer slots
+ * The integer values of the reference's GpuMatSource enum, verbatim (GPUStereoProcessor.h:21-57). */
+enum {
+    GIP_SIDE_L = 1 << 0,
+    GIP_SIDE_R = 1 << 1,
+    GIP_SIDE_MASK = GIP_SIDE_L | GIP_SIDE_R,
+    GIP_SRC_RAW = 1 << 2,
+    GIP_SRC_MONO = 1 << 3,
+    GIP_SRC_COLOR = 1 << 4,
+    GIP_SRC_RECT_MONO = 1 << 5,
+    GIP_SRC_RECT_COLOR = 1 << 6,
+    GIP_SRC_DISPARITY = 1 << 7,     /* int16 x16 fixed point (CPU StereoBM semantics) */
+    GIP_SRC_DISPARITY_32F = 1 << 8, /* float = d16/16 - (cx_l - cx_r)  (GPUStereoProcessor.cpp:320) */
+    GIP_SRC_DISPARITY_IMG = 1 << 9, /* BGRA8 */
+    GIP_SRC_POINTS2 = 1 << 10       /* 32FC3 xyz */
+};
+
+/* element types (OpenCV numbering so tests port 1:1): depth | ((cn-1) << 3) */
+enum { GIP_8U = 0, GIP_16U = 2, GIP_16S = 3, GIP_32F = 5 };
+#define GIP_MAKETYPE(depth, cn) ((depth) | (((cn) - 1) << 3))
+#define GIP_8UC1 GIP_MAKETYPE(GIP_8U, 1)
+#define GIP_8UC3 GIP_MAKETYPE(GIP_8U, 3)
+#define GIP_8UC4 GIP_MAKETYPE(GIP_8U, 4)
+#define GIP_16UC1 GIP_MAKETYPE(GIP_16U, 1)
+#define GIP_16SC1 GIP_MAKETYPE(GIP_16S, 1)
+#define GIP_32FC1 GIP_MAKETYPE(GIP_32F, 1)
+#define GIP_32FC3 GIP_MAKETYPE(GIP_32F, 3)
+
+enum { GIP_PREFILTER_NORMALIZED_RESPONSE = 0, GIP_PREFILTER_XSOBEL = 1 }; /* cv::StereoBM::PREFILTER_* */
+enum { GIP_INTER_NEAREST = 0, GIP_INTER_LINEAR = 1 };                     /* cv::InterpolationFlags */
+enum { GIP_BAYER_RGGB = 0, GIP_BAYER_BGGR = 1, GIP_BAYER_GBRG = 2, GIP_BAYER_GRBG = 3 };
+
+/* ConnectedTopics bit order (reference include/gpuimageproc/ConnectedTopics.h:11-21) */
+enum {
+    GIP_TOPIC_DEBAYER_MONO_LEFT = 1 << 0,
+    GIP_TOPIC_DEBAYER_MONO_RIGHT = 1 << 1,
+    GIP_TOPIC_DEBAYER_COLOR_LEFT = 1 << 2,
+    GIP_TOPIC_DEBAYER_COLOR_RIGHT = 1 << 3,
+    GIP_TOPIC_RECTIFY_MONO_LEFT = 1 << 4,
+    GIP_TOPIC_RECTIFY_MONO_RIGHT = 1 << 5,
+    GIP_TOPIC_RECTIFY_COLOR_LEFT = 1 << 6,
+    GIP_TOPIC_RECTIFY_COLOR_RIGHT = 1 << 7,
+    GIP_TOPIC_DISPARITY = 1 << 8,
+    GIP_TOPIC_DISPARITY_VIS = 1 << 9,
+    GIP_TOPIC_POINTCLOUD = 1 << 10
+};
+
+/* ------------------------------------------------------------------ parameter block
+ * Union of the reference's setters (GPUStereoProcessor.cpp:389-419, :202-208), cfg/GPU.cfg and the
+ * cv::StereoBM parameters its constructor mirrors into the CPU matcher (GPUStereoProcessor.cpp:18-38). */
+typedef struct gip_bm_params {
+    int32_t prefilter_type;      /* GIP_PREFILTER_* */
+    int32_t prefilter_size;      /* odd 5..255 (NORMALIZED_RESPONSE) */
+    int32_t prefilter_cap;       /* 1..63 */
+    int32_t block_size;          /* odd 5..255 ("correlation_window_size") */
+    int32_t min_disparity;       /* "disparity_min" */
+    int32_t num_disparities;     /* multiple of 16 ("disparity_range") */
+    int32_t texture_threshold;   /* >= 0 */
+    int32_t uniqueness_ratio;    /* >= 0, 0 disables */
+    int32_t disp12_max_diff;     /* < 0 disables the L/R consistency check */
+    int32_t speckle_window_size; /* StereoBM-internal speckle pass (0 = off) */
+    int32_t speckle_range;
+} gip_bm_params;
+
+/* sensor_msgs/CameraInfo fields the model needs (GPUStereoProcessor.cpp:41-53) */
+typedef struct gip_camera_info {
+    int32_t width, height;
+    double K[9];
+    double D[8];
+    int32_t nD;
+    double R[9];
+    double P[12];
+} gip_camera_info;
+
+/* ------------------------------------------------------------------ message PODs (the senders' payloads) */
+typedef struct gip_header {
+    uint32_t seq;
+    uint32_t stamp_sec, stamp_nsec;
+    char frame_id[64];
+} gip_header;
+
+/* sensor_msgs/Image as filled by GPUSenderImage::fillInData (GpuSenderImage.cpp:15-26) */
+typedef struct gip_image_msg {
+    gip_header header;
+    uint32_t height, width;
+    char encoding[16];
+    uint8_t is_bigendian;
+    uint32_t step;
+    uint8_t *data; /* height*step bytes, owned by the sender until gip_clean_senders */
+    size_t data_size;
+} gip_image_msg;
+
+/* stereo_msgs/DisparityImage as filled by GPUSenderDisparity::fillInData (GpuSenderDisparity.cpp:18-48) */
+typedef struct gip_disparity_msg {
+    gip_header header;
+    gip_image_msg image; /* 32FC1 */
+    float f, T;
+    uint32_t valid_x_offset, valid_y_offset, valid_width, valid_height;
+    float min_disparity, max_disparity, delta_d;
+} gip_disparity_msg;
+
+/* sensor_msgs/PointCloud2 as filled by GPUSenderPc2::fillInData (GpuSenderPc2.cpp:15-72) */
+typedef struct gip_pointfield {
+    char name[8];
+    uint32_t offset;
+    uint8_t datatype; /* 7 = FLOAT32 */
+    uint32_t count;
+} gip_pointfield;
+typedef struct gip_pointcloud2_msg {
+    gip_header header;
+    uint32_t height, width;
+    gip_pointfield fields[4];
+    uint32_t nfields;
+    uint8_t is_bigendian;
+    uint32_t point_step, row_step;
+    uint8_t *data;
+    size_t data_size;
+    uint8_t is_dense;
+} gip_pointcloud2_msg;
+
+typedef void (*gip_image_cb)(const gip_image_msg *, void *user);
+typedef void (*gip_disparity_cb)(const gip_disparity_msg *, void *user);
+typedef void (*gip_pointcloud2_cb)(const gip_pointcloud2_msg *, void *user);
+
+typedef struct gip_processor *gip_handle;
+typedef void *gip_stream; /* hipStream_t */
+
+/* ================================================================== handle API (mirrors GpuStereoProcessor) */
+/* ctor / dtor (GPUStereoProcessor.cpp:12-39).  device < 0 -> current device. */
+int gip_create(int device, gip_handle *out);
+int gip_destroy(gip_handle h);
+const char *gip_last_error(gip_handle h);
+const char *gip_status_string(int status);
+int gip_device_count(void);
+
+/* initStereoModel(CameraInfo, CameraInfo) / (left_cal_file, right_cal_file)  (GPUStereoProcessor.cpp:41-61) */
+int gip_init_stereo_model(gip_handle h, const gip_camera_info *left, const gip_camera_info *right);
+int gip_init_stereo_model_files(gip_handle h, const char *left_cal_file, const char *right_cal_file);
+int gip_is_stereo_model_initialised(gip_handle h); /* :63 */
+int gip_read_calibration(const char *file, gip_camera_info *out, char *camera_name, size_t name_len);
+/* model accessors used by senders/tests */
+int gip_model_size(gip_handle h, int *width, int *height);
+int gip_model_get(gip_handle h, double *fx, double *fy, double *cx_l, double *cy, double *cx_r, double *baseline, double Q[16]);
+/* remap tables as built on the host (double), for broadcasting to other ranks: map1 = w*h*2 int16, map2 = w*h uint16 */
+int gip_get_rectify_maps(gip_handle h, int side, int16_t *map1, uint16_t *map2);
+
+/* uploadMat / downloadMat (GPUStereoProcessor.cpp:89-117).  encoding may be NULL/"" */
+int gip_upload_mat(gip_handle h, int slot, const void *data, int rows, int cols, size_t step, int type, const char *encoding);
+int gip_download_mat(gip_handle h, int slot, void *dst, size_t dst_step);
+int gip_mat_info(gip_handle h, int slot, int *rows, int *cols, int *type);
+/* device pointer + pitch of a slot (for zero-copy interop); NULL when the slot is empty */
+int gip_mat_device_ptr(gip_handle h, int slot, void **dptr, size_t *pitch);
+
+/* convertRawToColor / convertRawToMono / convertColor (GPUStereoProcessor.cpp:65-88, :119-172) */
+int gip_convert_raw_to_color(gip_handle h, int side);
+int gip_convert_raw_to_mono(gip_handle h, int side);
+int gip_convert_color(gip_handle h, int src_slot, int dst_slot, const char *src_encoding, const char *dst_encoding);
+
+/* rectifyImage (GPU, :236-250).  The remap is the CPU oracle's fixed-point form (rectifyImageLeft/Right :252-262) */
+int gip_rectify_image(gip_handle h, int src_slot, int dst_slot, int interpolation);
+
+/* computeDisparity(GpuMatSource x3) (:264-303): writes dst (int16 x16) and the matching DISPARITY_32F slot */
+int gip_compute_disparity(gip_handle h, int left_slot, int right_slot, int disparity_slot);
+/* filterSpeckles(GpuMatSource) (:356-365): on device, asynchronous; no-op when max_speckle_size <= 0 */
+int gip_filter_speckles(gip_handle h, int disparity_slot);
+/* computeDisparityImage (:323-330) */
+int gip_compute_disparity_image(gip_handle h, int disparity_slot, int image_slot);
+/* projectDisparityTo3DPoints (:332-346) */
+int gip_project_disparity_to_3d_points(gip_handle h, int disparity_slot, int points_slot);
+
+/* enqueueSendImage / enqueueSendDisparity / enqueueSendPoints (:210-234) + GPUSenderIfc::enqueueSend
+ * (GpuSenderIfc.cpp:13-26): async D2H on the slot's stream, then the callback runs on a host thread
+ * (hipLaunchHostFunc).  cb may be NULL (the reference tests pass a NULL publisher).  sender_id (optional out)
+ * identifies the sender for gip_sender_was_sent / gip_sender_*_msg until gip_clean_senders. */
+int gip_enqueue_send_image(gip_handle h, int slot, const gip_header *header, const char *encoding, gip_image_cb cb, void *user, int *sender_id);
+int gip_enqueue_send_disparity(gip_handle h, int slot, const gip_header *header, gip_disparity_cb cb, void *user, int *sender_id);
+int gip_enqueue_send_points(gip_handle h, int points_slot, int color_slot, const gip_header *header, gip_pointcloud2_cb cb, void *user, int *sender_id);
+int gip_sender_was_sent(gip_handle h, int sender_id); /* GPUSenderIfc::wasDataSent */
+const gip_image_msg *gip_sender_image_msg(gip_handle h, int sender_id);
+const gip_disparity_msg *gip_sender_disparity_msg(gip_handle h, int sender_id);
+const gip_pointcloud2_msg *gip_sender_pointcloud2_msg(gip_handle h, int sender_id);
+int gip_clean_senders(gip_handle h); /* :387 */
+
+/* waitForStream / waitForAllStreams (:348-354) */
+int gip_wait_for_stream(gip_handle h, int slot_or_side);
+int gip_wait_for_all_streams(gip_handle h);
+
+/* setters (:389-419, :202-208); the extra four expose cv::StereoBM state the reference sets in its ctor */
+int gip_set_pre_filter_type(gip_handle h, int filter_type);
+int gip_set_refine_disparity(gip_handle h, int ref_disp); /* accepted, no effect on CPU-StereoBM semantics (cuda-only knob) */
+int gip_set_block_size(gip_handle h, int block_size);
+int gip_set_num_disparities(gip_handle h, int num_disp);
+int gip_set_min_disparity(gip_handle h, int min_disp);
+int gip_set_texture_threshold(gip_handle h, int threshold);
+int gip_set_max_speckle_size(gip_handle h, int max_speckle_size);
+int gip_get_max_speckle_size(gip_handle h);
+int gip_set_max_speckle_diff(gip_handle h, double max_speckle_diff);
+double gip_get_max_speckle_diff(gip_handle h);
+int gip_set_pre_filter_size(gip_handle h, int v);
+int gip_set_pre_filter_cap(gip_handle h, int v);
+int gip_set_uniqueness_ratio(gip_handle h, int v);
+int gip_set_disp12_max_diff(gip_handle h, int v);
+int gip_get_params(gip_handle h, gip_bm_params *out);
+int gip_set_params(gip_handle h, const gip_bm_params *p);
+
+/* The per-frame schedule of StereoProcessor::imageCb (reference src/StereoProcessor.cpp:157-298) for the
+ * connected-topic mask: upload both raws, run only the stages the mask needs, leave results in the slots.
+ * Synchronous like the reference (ends with waitForAllStreams). */
+int gip_process_pair(gip_handle h, const void *left_raw, const void *right_raw, int rows, int cols, size_t step, int type,
+                     const char *encoding, uint32_t connected_topics);
+
+/* ================================================================== stateless device kernels (gipk_*)
+ * All pointers are DEVICE pointers; pitches in BYTES unless suffixed _elems; `batch` images are laid out
+ * `*_bstride` BYTES apart; stream is a hipStream_t (NULL = default stream).  Launch errors are returned. */
+int gipk_cvt_bgr_to_gray(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int src_is_rgb,
+                         int batch, size_t src_bstride, size_t dst_bstride, gip_stream stream);
+int gipk_cvt_gray_to_bgr(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int batch,
+                         size_t src_bstride, size_t dst_bstride, gip_stream stream);
+int gipk_cvt_swap_rb(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int batch,
+                     size_t src_bstride, size_t dst_bstride, gip_stream stream);
+int gipk_cvt_bayer_to_bgr(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int pattern,
+                          int batch, size_t src_bstride, size_t dst_bstride, gip_stream stream);
+int gipk_cvt_bayer_to_gray(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int pattern,
+                           int batch, size_t src_bstride, size_t dst_bstride, gip_stream stream);
+int gipk_cvt_mono8_to_mono16(const uint8_t *src, size_t src_pitch, uint16_t *dst, size_t dst_pitch, int w, int h, int batch,
+                             size_t src_bstride, size_t dst_bstride, gip_stream stream);
+int gipk_cvt_mono16_to_mono8(const uint16_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int batch,
+                             size_t src_bstride, size_t dst_bstride, gip_stream stream);
+
+/* fixed-point bilinear remap (maps shared by all images of the batch); cn = 1 or 3 */
+int gipk_remap_u8(const uint8_t *src, size_t src_pitch, int sw, int sh, uint8_t *dst, size_t dst_pitch, int w, int h, int cn,
+                  const int16_t *map1, const uint16_t *map2, int batch, size_t src_bstride, size_t dst_bstride,
+                  gip_stream stream);
+
+int gipk_prefilter(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int prefilter_type,
+                   int prefilter_size, int prefilter_cap, int batch, size_t src_bstride, size_t dst_bstride,
+                   gip_stream stream);
+
+/* Block matching on PREFILTERED images: SAD + WTA + texture + uniqueness + sub-pixel -> int16 x16 and (optional) the
+ * min-SAD plane, i.e. the state findStereoCorrespondenceBM leaves before validateDisparity / ROI blanking. */
+int gipk_bm_match(const uint8_t *left, const uint8_t *right, size_t pitch, int w, int h, const gip_bm_params *p, int16_t *disp,
+                  size_t disp_pitch, int32_t *cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride,
+                  size_t cost_bstride, gip_stream stream);
+/* validateDisparity (if disp12_max_diff >= 0) + blanking outside the valid ROI */
+int gipk_bm_finalize(int16_t *disp, size_t disp_pitch, const int32_t *cost, size_t cost_pitch, int w, int h,
+                     const gip_bm_params *p, int batch, size_t disp_bstride, size_t cost_bstride, gip_stream stream);
+/* cv::StereoBM::compute: prefilter + match + finalize (+ StereoBM-internal speckle).  scratch: gipk_stereobm_scratch_bytes */
+size_t gipk_stereobm_scratch_bytes(int w, int h, int batch, const gip_bm_params *p);
+int gipk_stereobm(const uint8_t *left, const uint8_t *right, size_t pitch, int w, int h, const gip_bm_params *p, int16_t *disp,
+                  size_t disp_pitch, void *scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride,
+                  gip_stream stream);
+
+int gipk_disparity_to_f32(const int16_t *disp, size_t disp_pitch, float *dst, size_t dst_pitch, int w, int h, double cx_l,
+                          double cx_r, int batch, size_t disp_bstride, size_t dst_bstride, gip_stream stream);
+
+/* speckle filter on int16 maps; scratch >= gipk_speckle_scratch_bytes(w,h,batch) */
+size_t gipk_speckle_scratch_bytes(int w, int h, int batch);
+int gipk_filter_speckles(int16_t *disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff,
+                         void *scratch, size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream);
+
+/* reprojectImageTo3D on the float disparity (missing = the image minimum, i.e. `missing_value`) */
+int gipk_reproject_to_3d(const float *disp, size_t disp_pitch, float *xyz, size_t xyz_pitch, int w, int h, const double Q[16],
+                         float missing_value, int handle_missing, int batch, size_t disp_bstride, size_t xyz_bstride,
+                         gip_stream stream);
+/* PointCloud2 body from xyz + BGR */
+int gipk_pack_pointcloud2(const float *xyz, size_t xyz_pitch, const uint8_t *bgr, size_t bgr_pitch, uint8_t *out, int w, int h,
+                          int batch, size_t xyz_bstride, size_t bgr_bstride, size_t out_bstride, gip_stream stream);
+/* fused: int16 disparity (+ BGR) -> 32-byte PointCloud2 records, no xyz round trip */
+int gipk_disparity_to_pointcloud2(const int16_t *disp, size_t disp_pitch, const uint8_t *bgr, size_t bgr_pitch, uint8_t *out,
+                                  int w, int h, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
+                                  size_t disp_bstride, size_t bgr_bstride, size_t out_bstride, gip_stream stream);
+int gipk_draw_color_disp(const int16_t *disp, size_t disp_pitch, uint8_t *bgra, size_t bgra_pitch, int w, int h, int ndisp,
+                         int batch, size_t disp_bstride, size_t bgra_bstride, gip_stream stream);
+
+/* ================================================================== device-resident batch pipeline (benchmark path)
+ * One "step" = the whole chain over `batch` stereo pairs already resident in HBM:
+ *   raw (mono8 / bayer / bgr8) -> [debayer] -> rectify L,R (+ colour L) -> StereoBM -> speckle -> PointCloud2 (+f32 disparity)
+ * Remap tables come from the handle's model or are installed from device memory (received by RCCL broadcast). */
+typedef struct gip_batch_desc {
+    int32_t width, height, batch;
+    int32_t encoding;       /* 0 mono8, 1 bgr8, 2 rgb8, 3.. = 3 + GIP_BAYER_* */
+    uint32_t outputs;       /* GIP_TOPIC_* mask: DISPARITY and/or POINTCLOUD */
+    const uint8_t *left_raw, *right_raw; /* device, batch images, pitch = width*channels, contiguous */
+    int16_t *disparity;     /* device out: batch*h*w int16 (always written) */
+    float *disparity_f32;   /* device out or NULL */
+    uint8_t *pointcloud;    /* device out or NULL: batch*h*w*32 bytes */
+} gip_batch_desc;
+int gip_batch_set_maps_device(gip_handle h, int width, int height, const int16_t *map1_l, const uint16_t *map2_l,
+                              const int16_t *map1_r, const uint16_t *map2_r);
+int gip_batch_run(gip_handle h, const gip_batch_desc *desc, gip_stream stream);
+/* time (ms) the dominant kernel (SAD block matcher) took in the last gip_batch_run, from hipEvents on its stream;
+ * valid after the stream has been synchronised */
+int gip_batch_last_kernel_ms(gip_handle h, float *bm_ms, float *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUIMAGEPROC_HIP_H */

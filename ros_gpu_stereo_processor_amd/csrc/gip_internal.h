@@ -1,0 +1,58 @@
+// gip_internal.h -- shared helpers for the HIP implementation (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "gpuimageproc_hip.h"
+
+#define GIP_HIP_CHECK(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) { gip_note_hip_error(_e, #expr, __FILE__, __LINE__); return GIP_ERR_HIP; } \
+    } while (0)
+
+// Records the last HIP failure (thread-local text returned through gip_last_error).
+void gip_note_hip_error(hipError_t e, const char* what, const char* file, int line);
+const char* gip_last_hip_error_text();
+
+// Kernel launches cannot fail asynchronously in a way we can see here, but a bad configuration does.
+#define GIP_LAUNCH_CHECK() GIP_HIP_CHECK(hipGetLastError())
+
+static inline int gip_div_up(int a, int b) { return (a + b - 1) / b; }
+static inline size_t gip_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// Derived StereoBM geometry shared by host launchers and kernels (cv::StereoBM, stereobm.cpp).
+struct GipBmGeom {
+    int ndisp, mindisp, wsz, wsz2;
+    int lofs, rofs, width1;   // first output column, right-image offset, number of output columns
+    int roi_x, roi_y, roi_w, roi_h;  // getValidDisparityROI & image
+    int filtered;             // (mindisp - 1) * 16
+    bool degenerate;          // whole map FILTERED
+};
+
+static inline GipBmGeom gip_bm_geom(int w, int h, const gip_bm_params* p)
+{
+    GipBmGeom g;
+    g.ndisp = p->num_disparities; g.mindisp = p->min_disparity; g.wsz = p->block_size; g.wsz2 = g.wsz / 2;
+    int t = g.ndisp - 1 + g.mindisp;
+    g.lofs = t > 0 ? t : 0;
+    g.rofs = t < 0 ? -t : 0;
+    g.width1 = w - g.rofs - g.ndisp + 1;
+    // OpenCV's formula runs mindisp columns past the row end when minDisparity > 0; stop at the last image column
+    if (g.width1 > w - g.lofs) g.width1 = w - g.lofs;
+    g.filtered = (g.mindisp - 1) * 16;
+    int maxd = g.mindisp + g.ndisp - 1;
+    int xmin = (maxd > 0 ? maxd : 0) + g.wsz2;
+    int xmax = (w < w - g.mindisp ? w : w - g.mindisp) - g.wsz2;
+    int ymin = g.wsz2, ymax = h - g.wsz2;
+    g.roi_x = g.roi_y = g.roi_w = g.roi_h = 0;
+    if (xmax - xmin > 0 && ymax - ymin > 0) {
+        int x0 = xmin > 0 ? xmin : 0, x1 = xmax < w ? xmax : w, y0 = ymin > 0 ? ymin : 0, y1 = ymax < h ? ymax : h;
+        if (x1 > x0 && y1 > y0) { g.roi_x = x0; g.roi_y = y0; g.roi_w = x1 - x0; g.roi_h = y1 - y0; }
+    }
+    g.degenerate = (g.lofs >= w || g.rofs >= w || g.width1 < 1 || g.roi_w <= 0 || g.roi_h <= 0);
+    return g;
+}
+
+int gip_validate_bm_params(const gip_bm_params* p, int w, int h);

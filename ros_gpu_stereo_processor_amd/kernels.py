@@ -1,0 +1,202 @@
+"""Device-pointer front-end of the gipk_* kernel launchers for torch CUDA tensors.
+
+torch is plumbing only (HBM allocations, streams): every function launches hand-written HIP kernels through the C-ABI
+on the tensors' storage.  Inputs are (B, H, W[, C]) or (H, W[, C]) contiguous CUDA tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ck(rc):
+    if rc != capi.OK:
+        raise capi.GipError(rc, "kernel launcher")
+
+
+def _b(t, nd):
+    """-> (tensor with batch dim, batch)"""
+    if t.dim() == nd:
+        t = t.unsqueeze(0)
+    assert t.is_cuda and t.is_contiguous(), "contiguous CUDA tensor required"
+    return t, t.shape[0]
+
+
+def bm_params(**kw):
+    d = dict(prefilter_type=capi.PREFILTER_XSOBEL, prefilter_size=9, prefilter_cap=31, block_size=21, min_disparity=0, num_disparities=64,
+             texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=-1, speckle_window_size=0, speckle_range=0)
+    d.update(kw)
+    return capi.BMParams(**d)
+
+
+def _cvt(name, src, out_c, out_dtype, *extra, src_nd):
+    L = capi.lib()
+    s, B = _b(src, src_nd)
+    H, W = s.shape[1], s.shape[2]
+    shape = (B, H, W) if out_c == 1 else (B, H, W, out_c)
+    dst = torch.empty(shape, dtype=out_dtype, device=s.device)
+    sp = s.stride(1) * s.element_size()
+    dp = dst.stride(1) * dst.element_size()
+    _ck(getattr(L, name)(s.data_ptr(), sp, dst.data_ptr(), dp, W, H, *extra, B, s.stride(0) * s.element_size(), dst.stride(0) * dst.element_size(),
+                         _stream()))
+    return dst if src.dim() == src_nd + 1 else dst[0]
+
+
+def bgr_to_gray(src, src_is_rgb=False):
+    return _cvt("gipk_cvt_bgr_to_gray", src, 1, torch.uint8, int(src_is_rgb), src_nd=3)
+
+
+def gray_to_bgr(src):
+    return _cvt("gipk_cvt_gray_to_bgr", src, 3, torch.uint8, src_nd=2)
+
+
+def swap_rb(src):
+    return _cvt("gipk_cvt_swap_rb", src, 3, torch.uint8, src_nd=3)
+
+
+def bayer_to_bgr(src, encoding):
+    return _cvt("gipk_cvt_bayer_to_bgr", src, 3, torch.uint8, capi.BAYER[encoding], src_nd=2)
+
+
+def bayer_to_gray(src, encoding):
+    return _cvt("gipk_cvt_bayer_to_gray", src, 1, torch.uint8, capi.BAYER[encoding], src_nd=2)
+
+
+def mono8_to_mono16(src):
+    return _cvt("gipk_cvt_mono8_to_mono16", src, 1, torch.int16, src_nd=2)  # bit pattern of uint16
+
+
+def mono16_to_mono8(src):
+    return _cvt("gipk_cvt_mono16_to_mono8", src, 1, torch.uint8, src_nd=2)
+
+
+def remap(src, map1, map2):
+    """src (B,H,W) or (B,H,W,3) uint8; map1 (h,w,2) int16; map2 (h,w) int16-bit-pattern of uint16."""
+    L = capi.lib()
+    cn = 3 if (src.dim() == 4 or (src.dim() == 3 and src.shape[-1] == 3 and map1.shape[1] != src.shape[-1])) else 1
+    s, B = _b(src, 2 if cn == 1 else 3)
+    sh, sw = s.shape[1], s.shape[2]
+    h, w = map2.shape
+    dst = torch.empty((B, h, w) if cn == 1 else (B, h, w, 3), dtype=torch.uint8, device=s.device)
+    _ck(L.gipk_remap_u8(s.data_ptr(), sw * cn, sw, sh, dst.data_ptr(), w * cn, w, h, cn, map1.data_ptr(), map2.data_ptr(), B, sh * sw * cn, h * w * cn,
+                        _stream()))
+    return dst if src.dim() == (3 if cn == 1 else 4) else dst[0]
+
+
+def prefilter(src, prefilter_type, prefilter_size, prefilter_cap):
+    L = capi.lib()
+    s, B = _b(src, 2)
+    H, W = s.shape[1], s.shape[2]
+    dst = torch.empty_like(s)
+    _ck(L.gipk_prefilter(s.data_ptr(), W, dst.data_ptr(), W, W, H, prefilter_type, prefilter_size, prefilter_cap, B, H * W, H * W, _stream()))
+    return dst if src.dim() == 3 else dst[0]
+
+
+def bm_match(left_f, right_f, params, want_cost=True):
+    L = capi.lib()
+    l, B = _b(left_f, 2)
+    r, _ = _b(right_f, 2)
+    H, W = l.shape[1], l.shape[2]
+    disp = torch.empty((B, H, W), dtype=torch.int16, device=l.device)
+    cost = torch.zeros((B, H, W), dtype=torch.int32, device=l.device) if want_cost else None
+    _ck(L.gipk_bm_match(l.data_ptr(), r.data_ptr(), W, W, H, C.byref(params), disp.data_ptr(), W * 2, cost.data_ptr() if want_cost else None, W * 4, B,
+                        H * W, H * W * 2, H * W * 4, _stream()))
+    if left_f.dim() == 2:
+        return disp[0], (cost[0] if want_cost else None)
+    return disp, cost
+
+
+def bm_finalize(disp, cost, params):
+    L = capi.lib()
+    d, B = _b(disp, 2)
+    H, W = d.shape[1], d.shape[2]
+    _ck(L.gipk_bm_finalize(d.data_ptr(), W * 2, cost.data_ptr() if cost is not None else None, W * 4, W, H, C.byref(params), B, H * W * 2, H * W * 4,
+                           _stream()))
+    return disp
+
+
+def stereobm(left, right, params):
+    """cv::StereoBM::compute on (B,H,W) uint8 rectified pairs -> int16 x16."""
+    L = capi.lib()
+    l, B = _b(left, 2)
+    r, _ = _b(right, 2)
+    H, W = l.shape[1], l.shape[2]
+    disp = torch.empty((B, H, W), dtype=torch.int16, device=l.device)
+    nbytes = L.gipk_stereobm_scratch_bytes(W, H, B, C.byref(params))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=l.device)
+    _ck(L.gipk_stereobm(l.data_ptr(), r.data_ptr(), W, W, H, C.byref(params), disp.data_ptr(), W * 2, scratch.data_ptr(), nbytes, B, H * W, H * W * 2,
+                        _stream()))
+    return disp if left.dim() == 3 else disp[0]
+
+
+def disparity_to_f32(disp, cx_l, cx_r):
+    L = capi.lib()
+    d, B = _b(disp, 2)
+    H, W = d.shape[1], d.shape[2]
+    out = torch.empty((B, H, W), dtype=torch.float32, device=d.device)
+    _ck(L.gipk_disparity_to_f32(d.data_ptr(), W * 2, out.data_ptr(), W * 4, W, H, float(cx_l), float(cx_r), B, H * W * 2, H * W * 4, _stream()))
+    return out if disp.dim() == 3 else out[0]
+
+
+def filter_speckles(disp, new_val, max_speckle_size, max_diff):
+    """in place on an int16 (B,H,W) tensor"""
+    L = capi.lib()
+    d, B = _b(disp, 2)
+    H, W = d.shape[1], d.shape[2]
+    nbytes = L.gipk_speckle_scratch_bytes(W, H, B)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=d.device)
+    _ck(L.gipk_filter_speckles(d.data_ptr(), W * 2, W, H, int(new_val), int(max_speckle_size), int(max_diff), scratch.data_ptr(), nbytes, B, H * W * 2,
+                               _stream()))
+    return disp
+
+
+def _q(Q):
+    return (C.c_double * 16)(*[float(v) for v in Q.reshape(-1)])
+
+
+def reproject_to_3d(disp_f32, Q, missing_value, handle_missing=True):
+    L = capi.lib()
+    d, B = _b(disp_f32, 2)
+    H, W = d.shape[1], d.shape[2]
+    out = torch.empty((B, H, W, 3), dtype=torch.float32, device=d.device)
+    _ck(L.gipk_reproject_to_3d(d.data_ptr(), W * 4, out.data_ptr(), W * 12, W, H, _q(Q), C.c_float(missing_value), int(handle_missing), B, H * W * 4,
+                               H * W * 12, _stream()))
+    return out if disp_f32.dim() == 3 else out[0]
+
+
+def pack_pointcloud2(xyz, bgr):
+    L = capi.lib()
+    p, B = _b(xyz, 3)
+    c, _ = _b(bgr, 3)
+    H, W = p.shape[1], p.shape[2]
+    out = torch.empty((B, H, W, 32), dtype=torch.uint8, device=p.device)
+    _ck(L.gipk_pack_pointcloud2(p.data_ptr(), W * 12, c.data_ptr(), W * 3, out.data_ptr(), W, H, B, H * W * 12, H * W * 3, H * W * 32, _stream()))
+    return out if xyz.dim() == 4 else out[0]
+
+
+def disparity_to_pointcloud2(disp, bgr, Q, cx_l, cx_r, min_disparity):
+    L = capi.lib()
+    d, B = _b(disp, 2)
+    H, W = d.shape[1], d.shape[2]
+    out = torch.empty((B, H, W, 32), dtype=torch.uint8, device=d.device)
+    cptr = None
+    if bgr is not None:
+        c, _ = _b(bgr, 3)
+        cptr = c.data_ptr()
+    _ck(L.gipk_disparity_to_pointcloud2(d.data_ptr(), W * 2, cptr, W * 3, out.data_ptr(), W, H, _q(Q), float(cx_l), float(cx_r), int(min_disparity), B,
+                                        H * W * 2, H * W * 3, H * W * 32, _stream()))
+    return out if disp.dim() == 3 else out[0]
+
+
+def draw_color_disp(disp, ndisp):
+    L = capi.lib()
+    d, B = _b(disp, 2)
+    H, W = d.shape[1], d.shape[2]
+    out = torch.empty((B, H, W, 4), dtype=torch.uint8, device=d.device)
+    _ck(L.gipk_draw_color_disp(d.data_ptr(), W * 2, out.data_ptr(), W * 4, W, H, int(ndisp), B, H * W * 2, H * W * 4, _stream()))
+    return out if disp.dim() == 3 else out[0]
