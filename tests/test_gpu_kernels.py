@@ -1,0 +1,286 @@
+"""GPU parity tests (-m gpu): every hand-written HIP kernel, called through the C-ABI (gipk_* launchers), against the CPU
+oracle on the same seeded inputs.  Integer / byte results must be bit-exact; float results state their tolerance."""
+import numpy as np
+import pytest
+
+from ros_gpu_stereo_processor_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _n(t):
+    return t.cpu().numpy()
+
+
+# ---------------------------------------------------------------- colour
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (37, 53), (480, 752)])
+def test_colour_conversions(gpu, oracle, shape):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    rng = np.random.default_rng(11)
+    h, w = shape
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    mono = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    assert np.array_equal(_n(K.bgr_to_gray(_t(bgr, gpu), False)), oracle.bgr_to_gray(bgr, False))
+    assert np.array_equal(_n(K.bgr_to_gray(_t(bgr, gpu), True)), oracle.bgr_to_gray(bgr, True))
+    assert np.array_equal(_n(K.gray_to_bgr(_t(mono, gpu))), oracle.gray_to_bgr(mono))
+    assert np.array_equal(_n(K.swap_rb(_t(bgr, gpu))), oracle.swap_rb(bgr))
+    for enc in ("bayer_rggb8", "bayer_bggr8", "bayer_gbrg8", "bayer_grbg8"):
+        assert np.array_equal(_n(K.bayer_to_bgr(_t(mono, gpu), enc)), oracle.bayer_to_bgr(mono, enc)), enc
+        assert np.array_equal(_n(K.bayer_to_gray(_t(mono, gpu), enc)), oracle.bayer_to_gray(mono, enc)), enc
+    m16 = _n(K.mono8_to_mono16(_t(mono, gpu))).view(np.uint16)
+    assert np.array_equal(m16, oracle.mono8_to_mono16(mono))
+    big = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    assert np.array_equal(_n(K.mono16_to_mono8(_t(big.view(np.int16), gpu))), oracle.mono16_to_mono8(big))
+
+
+def test_rgb_to_gray_reference_golden(gpu, aloe):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    assert np.array_equal(_n(K.bgr_to_gray(_t(aloe["left_rgb"], gpu), True)), aloe["left_mono"])
+
+
+def test_colour_batch(gpu, oracle):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    rng = np.random.default_rng(12)
+    raw = rng.integers(0, 256, (3, 20, 34), dtype=np.uint8)
+    out = _n(K.bayer_to_gray(_t(raw, gpu), "bayer_rggb8"))
+    for b in range(3):
+        assert np.array_equal(out[b], oracle.bayer_to_gray(raw[b], "bayer_rggb8"))
+
+
+# ---------------------------------------------------------------- remap
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_remap_bit_exact_and_reference_golden(gpu, oracle, kitchen, calib, side):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    c = calib[side]
+    m1, m2 = oracle.init_undistort_rectify_map(c["K"], c["D"], c["R"], c["P"], c["width"], c["height"])
+    raw = kitchen[side + "_raw"]
+    got = _n(K.remap(_t(raw, gpu), _t(m1, gpu), _t(m2.view(np.int16), gpu)))
+    assert np.array_equal(got, oracle.remap(raw, m1, m2))  # same tables -> bit exact
+    diff = np.abs(got.astype(int) - kitchen[side + "_rect"].astype(int))  # reference golden (RectifyMonoGpu, UTest.cpp:262-288)
+    assert diff.max() <= 2 and (diff > 0).mean() <= 0.0002
+    # 3-channel
+    bgr = np.stack([raw, 255 - raw, raw // 2], -1)
+    got3 = _n(K.remap(_t(bgr, gpu), _t(m1, gpu), _t(m2.view(np.int16), gpu)))
+    assert np.array_equal(got3, oracle.remap(bgr, m1, m2))
+
+
+def test_remap_out_of_range_taps(gpu, oracle):
+    """maps pointing outside the source (BORDER_CONSTANT 0), including the half-outside taps"""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    rng = np.random.default_rng(13)
+    src = rng.integers(1, 256, (16, 20), dtype=np.uint8)
+    m1 = rng.integers(-3, 24, (30, 40, 2)).astype(np.int16)
+    m2 = rng.integers(0, 1024, (30, 40)).astype(np.uint16)
+    got = _n(K.remap(_t(src, gpu), _t(m1, gpu), _t(m2.view(np.int16), gpu)))
+    assert np.array_equal(got, oracle.remap(src, m1, m2))
+
+
+# ---------------------------------------------------------------- prefilter
+@pytest.mark.parametrize("shape", [(480, 752), (33, 47), (2, 9)])
+def test_prefilters(gpu, oracle, shape):
+    from ros_gpu_stereo_processor_amd import kernels as K, capi
+    rng = np.random.default_rng(14)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    for cap in (31, 63, 5):
+        assert np.array_equal(_n(K.prefilter(_t(img, gpu), capi.PREFILTER_XSOBEL, 9, cap)), oracle.prefilter_xsobel(img, cap))
+    if shape[0] >= 16:
+        for ws in (5, 9, 21):
+            assert np.array_equal(_n(K.prefilter(_t(img, gpu), capi.PREFILTER_NORMALIZED_RESPONSE, ws, 31)), oracle.prefilter_norm(img, ws, 31)), ws
+
+
+# ---------------------------------------------------------------- block matcher
+def _prefiltered_pair(oracle, w, h, ndisp, seed):
+    l, r, _ = synth.rectified_pair(w, h, min(ndisp, max(16, w // 3)), seed)
+    return oracle.prefilter_xsobel(l, 31), oracle.prefilter_xsobel(r, 31)
+
+
+BM_CASES = [
+    # (w, h, ndisp, block, mindisp, tex, uniq, disp12)
+    (160, 60, 16, 5, 0, 10, 15, -1),
+    (160, 60, 16, 5, 0, 10, 15, 1),
+    (200, 64, 32, 9, 0, 10, 15, 0),
+    (200, 64, 48, 11, 0, 0, 0, 0),       # the reference tests' configureProcessor-like set (UTest.cpp:78-87) at small size
+    (320, 70, 64, 15, 0, 10, 15, 1),
+    (320, 70, 96, 7, 0, 5, 10, 2),
+    (400, 50, 128, 9, 0, 10, 15, 1),
+    (400, 80, 128, 21, 0, 10, 15, 0),
+    (600, 48, 256, 21, 0, 10, 15, 1),
+    (200, 64, 32, 9, -8, 10, 15, 1),     # negative minDisparity, lofs > 0
+    (200, 64, 16, 9, -24, 10, 15, 1),    # negative minDisparity, rofs > 0
+    (200, 64, 32, 9, 6, 10, 15, 1),      # positive minDisparity
+    (131, 37, 16, 5, 0, 10, 15, 1),      # ragged sizes
+    (97, 33, 48, 13, 0, 3, 0, 0),
+    (64, 64, 64, 5, 0, 10, 15, 1),       # width1 == 1
+    (300, 40, 80, 31, 0, 10, 15, 1),     # largest block of the u16 path
+]
+
+
+@pytest.mark.parametrize("case", BM_CASES)
+def test_bm_match_bit_exact(gpu, oracle, case):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    w, h, nd, block, mind, tex, uniq, d12 = case
+    lf, rf = _prefiltered_pair(oracle, w, h, nd, seed=sum(case))
+    po = oracle.bm_params(block_size=block, num_disparities=nd, min_disparity=mind, texture_threshold=tex, uniqueness_ratio=uniq, disp12_max_diff=d12)
+    pg = K.bm_params(block_size=block, num_disparities=nd, min_disparity=mind, texture_threshold=tex, uniqueness_ratio=uniq, disp12_max_diff=d12)
+    exp_d, exp_c = oracle.bm_match(lf, rf, po)
+    got_d, got_c = K.bm_match(_t(lf, gpu), _t(rf, gpu), pg)
+    got_d, got_c = _n(got_d), _n(got_c)
+    if d12 < 0:
+        # border columns (clamped windows) only feed the L/R check; without it they are blanked later and not computed
+        roi = oracle.valid_disparity_roi(w, h, po)
+        sl = (slice(roi[1], roi[1] + roi[3]), slice(roi[0], roi[0] + roi[2]))
+        assert np.array_equal(got_d[sl], exp_d[sl])
+    else:
+        assert np.array_equal(got_d, exp_d)
+        valid = exp_d != (mind - 1) * 16
+        assert np.array_equal(got_c[valid], exp_c[valid])
+    # full compute (validate + blanking) must agree everywhere
+    exp = oracle.stereobm(*_raw_for(case), po)
+    got = _n(K.stereobm(_t(_raw_for(case)[0], gpu), _t(_raw_for(case)[1], gpu), pg))
+    assert np.array_equal(got, exp)
+
+
+_RAW_CACHE = {}
+
+
+def _raw_for(case):
+    if case not in _RAW_CACHE:
+        w, h, nd = case[0], case[1], case[2]
+        l, r, _ = synth.rectified_pair(w, h, min(nd, max(16, w // 3)), seed=sum(case) + 1)
+        _RAW_CACHE[case] = (l, r)
+    return _RAW_CACHE[case]
+
+
+def test_stereobm_norm_prefilter_and_batch(gpu, oracle):
+    from ros_gpu_stereo_processor_amd import kernels as K, capi
+    pairs = [synth.rectified_pair(256, 72, 64, seed=s)[:2] for s in (21, 22, 23)]
+    L = np.stack([p[0] for p in pairs])
+    R = np.stack([p[1] for p in pairs])
+    kw = dict(prefilter_type=capi.PREFILTER_NORMALIZED_RESPONSE, prefilter_size=5, block_size=15, num_disparities=64, texture_threshold=10,
+              uniqueness_ratio=0, disp12_max_diff=0)
+    got = _n(K.stereobm(_t(L, gpu), _t(R, gpu), K.bm_params(**kw)))
+    for b in range(3):
+        assert np.array_equal(got[b], oracle.stereobm(L[b], R[b], oracle.bm_params(**kw))), b
+
+
+def test_stereobm_kitchen_fixture(gpu, oracle, kitchen):
+    """C1 (BASELINE.json configs[0]): the reference's rectified fixture pair, ndisp 64 block 15, OpenCV defaults and the
+    reference-effective set (texture 3, uniqueness 0, disp12MaxDiff 0)."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    l, r = kitchen["left_rect"], kitchen["right_rect"]
+    for kw in (dict(block_size=15, num_disparities=64), dict(block_size=15, num_disparities=64, texture_threshold=3, uniqueness_ratio=0, disp12_max_diff=0),
+               dict(block_size=19, num_disparities=48, prefilter_size=5, texture_threshold=3, uniqueness_ratio=0, disp12_max_diff=0)):
+        exp = oracle.stereobm(l, r, oracle.bm_params(**kw))
+        got = _n(K.stereobm(_t(l, gpu), _t(r, gpu), K.bm_params(**kw)))
+        assert np.array_equal(got, exp), kw
+        assert (exp != -16).mean() > 0.05
+
+
+def test_stereobm_degenerate_and_errors(gpu, oracle):
+    from ros_gpu_stereo_processor_amd import kernels as K, capi
+    l, r, _ = synth.rectified_pair(40, 30, 16, seed=3)
+    # ndisp wider than the image: everything FILTERED
+    p = K.bm_params(block_size=5, num_disparities=64)
+    assert (_n(K.stereobm(_t(l, gpu), _t(r, gpu), p)) == -16).all()
+    assert (oracle.stereobm(l, r, oracle.bm_params(block_size=5, num_disparities=64)) == -16).all()
+    for bad in (dict(block_size=4), dict(block_size=41), dict(num_disparities=20), dict(prefilter_cap=64), dict(texture_threshold=-1)):
+        with pytest.raises(capi.GipError):
+            K.stereobm(_t(l, gpu), _t(r, gpu), K.bm_params(**{**dict(block_size=5, num_disparities=16), **bad}))
+    with pytest.raises(capi.GipError) as e:  # u16 cost range exceeded -> explicit UNSUPPORTED, never a silent wrong answer
+        big = synth.rectified_pair(200, 120, 16, seed=4)
+        K.stereobm(_t(big[0], gpu), _t(big[1], gpu), K.bm_params(block_size=51, num_disparities=16))
+    assert e.value.status == capi.ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------- post-processing
+def test_speckle_filter_bit_exact(gpu, oracle):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    rng = np.random.default_rng(15)
+    imgs = []
+    for i in range(3):
+        a = (rng.integers(0, 8, (90, 130)) * 16).astype(np.int16)
+        a[rng.random(a.shape) < 0.25] = -16
+        a[20:60, 30:100] = 5 * 16 + (np.arange(70) // 8)[None, :]  # one large smooth region
+        imgs.append(a)
+    batch = np.stack(imgs)
+    for max_size, max_diff in ((10, 16), (800, 80), (0, 0), (40, 0)):
+        got = _n(K.filter_speckles(_t(batch.copy(), gpu), -16, max_size, max_diff))
+        for b in range(3):
+            assert np.array_equal(got[b], oracle.filter_speckles(batch[b], -16, max_size, max_diff)), (max_size, max_diff, b)
+
+
+def test_speckle_on_real_disparity(gpu, oracle, kitchen):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    d = oracle.stereobm(kitchen["left_rect"], kitchen["right_rect"], oracle.bm_params(block_size=15, num_disparities=64))
+    exp = oracle.filter_speckles(d, -16, 800, 5 * 16)
+    got = _n(K.filter_speckles(_t(d.copy(), gpu), -16, 800, 5 * 16))
+    assert np.array_equal(got, exp)
+    assert (exp != d).any()  # the filter did remove something
+
+
+def test_disparity_f32_reproject_pointcloud(gpu, oracle, calib, kitchen):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    Pl, Pr = calib["left"]["P"], calib["right"]["P"]
+    Q = oracle.stereo_q(Pl, Pr)
+    d16 = oracle.stereobm(kitchen["left_rect"], kitchen["right_rect"], oracle.bm_params(block_size=15, num_disparities=64))
+    f_exp = oracle.disparity_to_f32(d16, Pl[2], Pr[2])
+    f_got = _n(K.disparity_to_f32(_t(d16, gpu), Pl[2], Pr[2]))
+    assert np.array_equal(f_got, f_exp)  # one float multiply + one add, contraction off on both sides
+    xyz_exp = oracle.reproject_to_3d(f_exp, Q, True)
+    xyz_got = _n(K.reproject_to_3d(_t(f_exp, gpu), Q, float(f_exp.min()), True))
+    # double arithmetic, float store; OpenCV accumulates q += Q[0] per column, the kernel evaluates Q[0]*x: <= 1 float ulp
+    assert np.array_equal(np.isinf(xyz_got), np.isinf(xyz_exp))
+    fin = np.isfinite(xyz_exp)
+    assert np.allclose(xyz_got[fin], xyz_exp[fin], rtol=2.4e-7, atol=0)
+    assert np.array_equal(xyz_got[..., 2] == 10000, xyz_exp[..., 2] == 10000)
+    bgr = np.stack([kitchen["left_rect"]] * 3, -1)
+    pc_exp = oracle.pack_pointcloud2(xyz_exp, bgr)
+    pc_got = _n(K.pack_pointcloud2(_t(xyz_exp, gpu), _t(bgr, gpu)))
+    assert np.array_equal(pc_got, pc_exp)  # byte image identical (NaN pattern included) given identical xyz
+    # fused disparity -> cloud: same record layout / NaN mask / colour bytes, xyz within 1 ulp
+    pc_fused = _n(K.disparity_to_pointcloud2(_t(d16, gpu), _t(bgr, gpu), Q, Pl[2], Pr[2], 0))
+    fx = pc_fused[..., :12].copy().view(np.float32)
+    ex = pc_exp[..., :12].copy().view(np.float32)
+    assert np.array_equal(np.isnan(fx), np.isnan(ex))
+    ok = ~np.isnan(ex)
+    assert np.allclose(fx[ok], ex[ok], rtol=2.4e-7, atol=0)
+    assert np.array_equal(pc_fused[..., 12:], pc_exp[..., 12:])
+
+
+def test_draw_color_disp(gpu, oracle):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    d16 = np.arange(-16, -16 + 2100, dtype=np.int32).reshape(42, 50).astype(np.int16)
+    for nd in (48, 128):
+        assert np.array_equal(_n(K.draw_color_disp(_t(d16, gpu), nd)), oracle.draw_color_disp(d16, nd))
+
+
+def test_full_size_properties(gpu, oracle):
+    """BASELINE configs[1] size (1242x375, ndisp 128, block 9) on a batch: sampled rows bit-exact vs the oracle, plus the
+    size-independent invariants (range, FILTERED outside the ROI, idempotent speckle filter)."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    B = 4
+    pairs = [synth.rectified_pair(1242, 375, 128, seed=40 + i) for i in range(B)]
+    L = np.stack([p[0] for p in pairs])
+    R = np.stack([p[1] for p in pairs])
+    kw = dict(block_size=9, num_disparities=128, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1)
+    got = K.stereobm(_t(L, gpu), _t(R, gpu), K.bm_params(**kw))
+    g = _n(got)
+    exp0 = oracle.stereobm(L[0], R[0], oracle.bm_params(**kw))
+    assert np.array_equal(g[0], exp0)
+    exp3 = oracle.stereobm(L[3], R[3], oracle.bm_params(**kw))
+    assert np.array_equal(g[3], exp3)
+    valid = g != -16
+    assert g[valid].min() >= 0 and g[valid].max() <= 127 * 16
+    roi = oracle.valid_disparity_roi(1242, 375, oracle.bm_params(**kw))
+    mask = np.ones((375, 1242), bool)
+    mask[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]] = False
+    assert (g[:, mask] == -16).all()
+    once = K.filter_speckles(got.clone(), -16, 800, 80)
+    twice = K.filter_speckles(once.clone(), -16, 800, 80)
+    assert np.array_equal(_n(once), _n(twice))
+    assert np.array_equal(_n(once)[1], oracle.filter_speckles(g[1], -16, 800, 80))
