@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the stereo hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the whole per-frame chain (rectify L/R + colour L -> StereoBM with L/R check -> speckle filter ->
+float disparity + 32-byte PointCloud2 records) over one batch of synthetic stereo pairs that are already resident in HBM.
+Workload = BASELINE.json configs[1]: 1242x375 mono8, ndisp 128, block 9.  Frames are sharded across ranks (independent
+units, weak scaling): rank 0 builds the rectification tables on the host and broadcasts CameraInfo + tables once over
+RCCL; there is no data-path collective.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H, NDISP, BLOCK = 1242, 375, 128, 9
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def bm_kwargs():
+    # cv::StereoBM defaults (XSOBEL, cap 31, texture 10, uniqueness 15) + the L/R consistency check north_star asks for
+    return dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=BLOCK, min_disparity=0, num_disparities=NDISP,
+                texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+
+
+SPECKLE_SIZE, SPECKLE_DIFF = 800, 5.0  # cfg/GPU.cfg:34-35 defaults
+
+
+def make_inputs(batch, seed0, nseeds=4):
+    from ros_gpu_stereo_processor_amd import synth
+    calib = synth.scaled_calibration(W, H)
+    ls, rs = [], []
+    for i in range(nseeds):
+        l, r, _, _ = synth.raw_pair(W, H, NDISP, seed=seed0 + i, calib=calib)
+        ls.append(l)
+        rs.append(r)
+    idx = np.arange(batch) % nseeds
+    return np.stack(ls)[idx], np.stack(rs)[idx], calib
+
+
+def cpu_chain(O, lr, rr, calib, maps, po):
+    """The same chain on the host cores with the oracle (the restatement of the reference's CPU path)."""
+    rl, rrect = O.remap(lr, *maps[0]), O.remap(rr, *maps[1])
+    bgr = O.gray_to_bgr(rl)
+    d16 = O.stereobm(rl, rrect, po)
+    d16 = O.filter_speckles(d16, -16, SPECKLE_SIZE, int(SPECKLE_DIFF * 16))
+    d32 = O.disparity_to_f32(d16, calib["left"]["P"][2], calib["right"]["P"][2])
+    xyz = O.reproject_to_3d(d32, O.stereo_q(calib["left"]["P"], calib["right"]["P"]), True)
+    return d16, O.pack_pointcloud2(xyz, bgr)
+
+
+def cpu_baseline(lraw, rraw, calib, budget_s=12.0, max_pairs=64):
+    from oracle import oracle as O
+    maps = [O.init_undistort_rectify_map(calib[s]["K"], calib[s]["D"], calib[s]["R"], calib[s]["P"], W, H) for s in ("left", "right")]
+    po = O.bm_params(**bm_kwargs())
+    cpu_chain(O, lraw[0], rraw[0], calib, maps, po)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < max_pairs and (time.perf_counter() - t0) < budget_s:
+        cpu_chain(O, lraw[n % len(lraw)], rraw[n % len(rraw)], calib, maps, po)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 3), unit="stereo pairs/s", cores=O.num_threads(), kind="port",
+                sample="%d pairs of the same 1242x375 ndisp=128 block=9 chain (remap L/R, StereoBM+L/R check, speckle, reproject, PointCloud2 pack) "
+                       "in %.1f s with the C oracle (OpenMP over row stripes); OpenCV itself is not installable here" % (n, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    lraw, rraw, calib = make_inputs(B, seed0=100 + 16 * rank)
+    params = capi.BMParams(**bm_kwargs())
+    outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
+    pipe = BatchPipeline(W, H, calib, params, B, "mono8", outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True)
+
+    # rectification tables: rank 0's host-built tables, broadcast once over RCCL (xGMI); no per-frame collective follows
+    maps = pipe.host_maps_to_device() if rank == 0 else pipe.empty_maps()
+    if world > 1:
+        for m in maps:
+            dist.broadcast(m, src=0)
+    pipe.install_maps(maps)
+
+    left = torch.from_numpy(lraw).to(dev)
+    right = torch.from_numpy(rraw).to(dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pipe.run(left, right)
+    torch.cuda.synchronize()
+    pipe.timing_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run(left, right)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    bm_ms_sum, total_ms_sum, runs = pipe.timing_read()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / dt_max
+        bm_ms = bm_ms_sum / max(runs, 1)
+        # dominant kernel: k_bm_fast (SAD block matcher on the prefiltered rectified pair).  Algorithmic bytes per
+        # stereo pair = 4*W*H (prefiltered L + R read once, int16 disparity written once; SURVEY.md section 8d,
+        # "SAD-only kernel on rectified input"); one launch processes B pairs.
+        algo_bytes = 4.0 * W * H * B
+        achieved = algo_bytes / (bm_ms * 1e-3) / 1e9 if bm_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("batch") == B and tj.get("workload") == "1242x375_nd128_b9":
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "stereo pairs/sec + ms/frame disparity, 1242x375 ndisp=128 at 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * args.steps), 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "KITTI-size 1242x375 mono8, ndisp=128 block=9, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
+                                   "->speckle(800,5)->f32 disparity+PointCloud2", "pairs_per_step_per_gpu": B, "parallelism": "frame-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_bm_fast<64,3>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_ms": round(bm_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lraw[:4], rraw[:4], calib)
+        print(json.dumps(out), flush=True)
+    pipe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -329,6 +329,10 @@ int gip_batch_run(gip_handle h, const gip_batch_desc *desc, gip_stream stream);
 /* time (ms) the dominant kernel (SAD block matcher) took in the last gip_batch_run, from hipEvents on its stream;
  * valid after the stream has been synchronised */
 int gip_batch_last_kernel_ms(gip_handle h, float *bm_ms, float *total_ms);
+/* every gip_batch_run since the last reset records its own event pairs; read returns the sums (ms) and the run count.
+ * The stream(s) used must have been synchronised before reading. */
+int gip_batch_timing_reset(gip_handle h);
+int gip_batch_timing_read(gip_handle h, double *bm_ms_sum, double *total_ms_sum, int *runs);
 
 #ifdef __cplusplus
 }

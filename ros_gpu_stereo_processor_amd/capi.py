@@ -165,6 +165,8 @@ PROTOTYPES = {
     "gip_batch_set_maps_device": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "gip_batch_run": (_i, [_vp, C.POINTER(BatchDesc), _vp]),
     "gip_batch_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gip_batch_timing_reset": (_i, [_vp]),
+    "gip_batch_timing_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
 }
 
 _LIB = None

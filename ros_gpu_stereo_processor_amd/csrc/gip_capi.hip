@@ -104,8 +104,9 @@ struct gip_processor {
     std::vector<std::pair<void*, size_t>> pinned_pool;
     // batch pipeline
     DevBuf b_mono[2], b_color, b_rect[2], b_rect_color, b_f32;
-    hipEvent_t ev_bm0 = nullptr, ev_bm1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-    bool batch_timed = false;
+    // per-run timing events of the batch pipeline: 4 per run (bm0, bm1, total0, total1), grown on demand
+    std::vector<hipEvent_t> tev;
+    int timing_runs = 0;
 };
 
 namespace {
@@ -340,10 +341,6 @@ int gip_create(int device, gip_handle* out)
         delete h;
         return GIP_ERR_HIP;
     }
-    hipEventCreate(&h->ev_bm0);
-    hipEventCreate(&h->ev_bm1);
-    hipEventCreate(&h->ev_t0);
-    hipEventCreate(&h->ev_t1);
     gip_bm_params& p = h->params;
     p.prefilter_type = GIP_PREFILTER_XSOBEL;
     p.prefilter_size = 5;
@@ -384,9 +381,8 @@ int gip_destroy(gip_handle h)
     DevBuf* bufs[] = {&h->bm_scratch, &h->spk_scratch, &h->pc_dev, &h->b_mono[0], &h->b_mono[1], &h->b_color, &h->b_rect[0], &h->b_rect[1], &h->b_rect_color, &h->b_f32};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
-    hipEvent_t evs[] = {h->ev_bm0, h->ev_bm1, h->ev_t0, h->ev_t1};
-    for (hipEvent_t e : evs)
-        if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->tev)
+        if (e) (void)hipEventDestroy(e);
     if (h->l_strm) hipStreamDestroy(h->l_strm);
     if (h->r_strm) hipStreamDestroy(h->r_strm);
     delete h;
@@ -1055,7 +1051,14 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     gip_bm_params bp = h->params;
     bp.speckle_window_size = 0;  // the node-level speckle filter below is the one the reference runs
 #define B_STEP(expr, what) do { rc = (expr); if (rc != GIP_OK) return propagate(h, rc, what); } while (0)
-    H_HIP(h, hipEventRecord(h->ev_t0, st));
+    if (h->timing_runs >= 4096) h->timing_runs = 0;  // ring: the caller is expected to read/reset well before this
+    while ((int)h->tev.size() < 4 * (h->timing_runs + 1)) {
+        hipEvent_t e;
+        H_HIP(h, hipEventCreate(&e));
+        h->tev.push_back(e);
+    }
+    hipEvent_t* ev = &h->tev[4 * h->timing_runs];
+    H_HIP(h, hipEventRecord(ev[2], st));
     // stage 1: colour (StereoProcessor.cpp:183-217)
     const uint8_t* mono[2] = {d->left_raw, d->right_raw};
     const uint8_t* color_l = nullptr;
@@ -1103,8 +1106,8 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     }
     // stage 3: disparity + speckle (StereoProcessor.cpp:259-268)
     B_STEP(ensure_dev(h, h->bm_scratch, gipk_stereobm_scratch_bytes(w, hh, B, &bp)), "batch buffers");
-    g_bm_ev0 = h->ev_bm0;
-    g_bm_ev1 = h->ev_bm1;
+    g_bm_ev0 = ev[0];
+    g_bm_ev1 = ev[1];
     rc = gipk_stereobm((const uint8_t*)h->b_rect[0].p, (const uint8_t*)h->b_rect[1].p, w, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, npx,
                        npx * 2, st);
     g_bm_ev0 = g_bm_ev1 = nullptr;
@@ -1120,8 +1123,8 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     if (want_pc)
         B_STEP(gipk_disparity_to_pointcloud2(d->disparity, (size_t)w * 2, rect_color, (size_t)w * 3, d->pointcloud, w, hh, h->model.Q, h->model.left.cx(), h->model.right.cx(),
                                              bp.min_disparity, B, npx * 2, npx * 3, npx * 32, st), "pointcloud");
-    H_HIP(h, hipEventRecord(h->ev_t1, st));
-    h->batch_timed = true;
+    H_HIP(h, hipEventRecord(ev[3], st));
+    h->timing_runs++;
 #undef B_STEP
     return GIP_OK;
 }
@@ -1129,9 +1132,34 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
 int gip_batch_last_kernel_ms(gip_handle h, float* bm_ms, float* total_ms)
 {
     H_CHECK(h);
-    if (!h->batch_timed) return fail(h, GIP_ERR_INVALID_ARG, "no batch has run");
-    if (bm_ms) H_HIP(h, hipEventElapsedTime(bm_ms, h->ev_bm0, h->ev_bm1));
-    if (total_ms) H_HIP(h, hipEventElapsedTime(total_ms, h->ev_t0, h->ev_t1));
+    if (h->timing_runs <= 0) return fail(h, GIP_ERR_INVALID_ARG, "no batch has run");
+    hipEvent_t* ev = &h->tev[4 * (h->timing_runs - 1)];
+    if (bm_ms) H_HIP(h, hipEventElapsedTime(bm_ms, ev[0], ev[1]));
+    if (total_ms) H_HIP(h, hipEventElapsedTime(total_ms, ev[2], ev[3]));
+    return GIP_OK;
+}
+
+int gip_batch_timing_reset(gip_handle h)
+{
+    H_CHECK(h);
+    h->timing_runs = 0;
+    return GIP_OK;
+}
+
+int gip_batch_timing_read(gip_handle h, double* bm_ms_sum, double* total_ms_sum, int* runs)
+{
+    H_CHECK(h);
+    double a = 0, b = 0;
+    for (int i = 0; i < h->timing_runs; i++) {
+        float x = 0, y = 0;
+        H_HIP(h, hipEventElapsedTime(&x, h->tev[4 * i], h->tev[4 * i + 1]));
+        H_HIP(h, hipEventElapsedTime(&y, h->tev[4 * i + 2], h->tev[4 * i + 3]));
+        a += x;
+        b += y;
+    }
+    if (bm_ms_sum) *bm_ms_sum = a;
+    if (total_ms_sum) *total_ms_sum = b;
+    if (runs) *runs = h->timing_runs;
     return GIP_OK;
 }
 

@@ -86,8 +86,16 @@ __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, f
 
 // ---------------------------------------------------------------------------------------- speckle filter
 // cv::filterSpeckles = remove 4-connected components (neighbours joined when both != newVal and |diff| <= maxDiff) of
-// size <= maxSpeckleSize.  Components of a fixed symmetric graph => order independent => union-find gives the same
-// result bit for bit.  labels[] is one int per pixel (index of the parent), sizes[] one int per pixel.
+// size <= maxSpeckleSize.  Components of a fixed symmetric graph => order independent => a parallel union-find gives
+// the same result bit for bit.
+//
+// Run-based CCL (the union-find nodes are horizontal RUNS, not pixels, so the number of global atomics scales with the
+// number of run overlaps instead of the number of pixels):
+//   k_spk_runs   one workgroup per image row: every valid pixel gets the index of the first pixel of its run
+//                (segmented max-scan in LDS); run starts point to themselves; the last pixel of a run stores its length
+//   k_spk_merge  one union per maximal overlap segment between runs of adjacent rows (atomicMin union-find on run starts)
+//   k_spk_sizes  every run start: root = find(); atomicAdd(size[root], run length); path compression
+//   k_spk_apply  pixels whose component has <= maxSpeckleSize pixels become newVal
 __device__ __forceinline__ int uf_find(int* lab, int i)
 {
     // agent-scope relaxed loads: other workgroups (other XCDs) relink concurrently; a stale parent is still an
@@ -120,62 +128,109 @@ __device__ __forceinline__ void uf_union(int* lab, int a, int b)
     } while (!done);
 }
 
-__global__ void k_speckle_init(const int16_t* __restrict__ disp, size_t dpitch, int* __restrict__ lab, int* __restrict__ sizes, int w, int h,
-                               int new_val, size_t dbs)
+__device__ __forceinline__ bool spk_conn(int a, int b, int new_val, int max_diff)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    size_t npix = (size_t)w * h;
-    int i = y * w + x;
-    int v = ((const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs))[(size_t)y * dpitch + x];
-    lab[blockIdx.z * npix + i] = (v != new_val) ? i : -1;
-    sizes[blockIdx.z * npix + i] = 0;
+    int df = a - b;
+    return a != new_val && b != new_val && (df < 0 ? -df : df) <= max_diff;
 }
 
-__global__ void k_speckle_merge(const int16_t* __restrict__ disp, size_t dpitch, int* __restrict__ lab, int w, int h, int new_val, int max_diff,
-                                size_t dbs)
+constexpr int SPK_TPB = 256;
+
+// lab[i]: valid pixel -> index (within the frame) of its run's first pixel; invalid -> -1.   rlen[start] = run length.
+__global__ void __launch_bounds__(SPK_TPB) k_spk_runs(const int16_t* __restrict__ disp, size_t dpitch, int* __restrict__ lab, int* __restrict__ rlen,
+                                                       int* __restrict__ sizes, int w, int h, int new_val, int max_diff, size_t dbs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    short* row = (short*)smem_raw;                 // w values (+1 pad)
+    int* part = (int*)(smem_raw + (((size_t)w * 2 + 2 + 15) & ~(size_t)15));  // SPK_TPB partial maxima
+    const int y = blockIdx.x, t = threadIdx.x;
+    const int16_t* d = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
+    const size_t base = blockIdx.z * (size_t)w * h + (size_t)y * w;
+    for (int x = t; x < w; x += SPK_TPB) row[x] = d[x];
+    __syncthreads();
+    const int chunk = (w + SPK_TPB - 1) / SPK_TPB;
+    const int x0 = t * chunk, x1 = min(x0 + chunk, w);
+    // pass 1: last run start inside my chunk
+    int last = -1;
+    for (int x = x0; x < x1; x++) {
+        int v = row[x];
+        bool start = v != new_val && (x == 0 || !spk_conn(row[x - 1], v, new_val, max_diff));
+        if (start) last = x;
+    }
+    part[t] = last;
+    __syncthreads();
+    // inclusive max-scan over the partials (Hillis-Steele, 8 steps)
+    for (int off = 1; off < SPK_TPB; off <<= 1) {
+        int v = part[t];
+        int o = t >= off ? part[t - off] : -1;
+        __syncthreads();
+        part[t] = v > o ? v : o;
+        __syncthreads();
+    }
+    int running = t > 0 ? part[t - 1] : -1;
+    // pass 2: labels, run lengths
+    for (int x = x0; x < x1; x++) {
+        int v = row[x];
+        bool valid = v != new_val;
+        bool start = valid && (x == 0 || !spk_conn(row[x - 1], v, new_val, max_diff));
+        if (start) running = x;
+        lab[base + x] = valid ? y * w + running : -1;
+        sizes[base + x] = 0;
+        // rlen > 0 marks exactly the run starts: non-starts are zeroed here, a start is written by whichever thread
+        // owns the run's LAST pixel (disjoint addresses, every run has one last pixel)
+        if (!start) rlen[base + x] = 0;
+        bool last_of_run = valid && (x == w - 1 || !spk_conn(v, row[x + 1], new_val, max_diff));
+        if (last_of_run) rlen[base + running] = x - running + 1;
+    }
+}
+
+__global__ void k_spk_merge(const int16_t* __restrict__ disp, size_t dpitch, int* __restrict__ lab, int w, int h, int new_val, int max_diff, size_t dbs)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const int16_t* d = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs);
+    if (x >= w || y + 1 >= h) return;
+    const int16_t* d0 = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
+    const int16_t* d1 = d0 + dpitch;
+    int a = d0[x], b = d1[x];
+    if (!spk_conn(a, b, new_val, max_diff)) return;
+    if (x > 0) {
+        // the pair (x-1) already joins the same two runs: this vertical edge is redundant
+        int al = d0[x - 1], bl = d1[x - 1];
+        if (spk_conn(al, a, new_val, max_diff) && spk_conn(bl, b, new_val, max_diff) && spk_conn(al, bl, new_val, max_diff)) return;
+    }
     int* L = lab + blockIdx.z * (size_t)w * h;
-    int v = d[(size_t)y * dpitch + x];
-    if (v == new_val) return;
-    int i = y * w + x;
-    if (x + 1 < w) {
-        int q = d[(size_t)y * dpitch + x + 1];
-        int df = v - q;
-        if (q != new_val && (df < 0 ? -df : df) <= max_diff) uf_union(L, i, i + 1);
-    }
-    if (y + 1 < h) {
-        int q = d[(size_t)(y + 1) * dpitch + x];
-        int df = v - q;
-        if (q != new_val && (df < 0 ? -df : df) <= max_diff) uf_union(L, i, i + w);
-    }
+    const int i = y * w + x;
+    // entries of non-start pixels are never modified (atomics only hit run starts), so they still name the run start
+    uf_union(L, L[i], L[i + w]);
 }
 
-__global__ void k_speckle_count(int* __restrict__ lab, int* __restrict__ sizes, int w, int h)
+__global__ void k_spk_sizes(int* __restrict__ lab, const int* __restrict__ rlen, int* __restrict__ sizes, int w, int h)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
-    size_t base = blockIdx.z * (size_t)w * h;
-    int i = y * w + x;
+    const size_t base = blockIdx.z * (size_t)w * h;
+    const int i = y * w + x;
     int p = lab[base + i];
     if (p < 0) return;
-    int root = i;
-    while (p != root) { root = p; p = lab[base + root]; }   // previous kernel is complete: plain loads are coherent
-    lab[base + i] = root;   // full compression (roots never change in this kernel; writes are idempotent)
-    atomicAdd(&sizes[base + root], 1);
+    const int len = rlen[base + i];
+    if (len <= 0) return;  // not a run start
+    int root = p;
+    int q = lab[base + root];
+    while (q != root) { root = q; q = lab[base + root]; }   // the merge kernel is complete: plain loads are coherent
+    lab[base + i] = root;                                    // compression: starts now point straight at their root
+    atomicAdd(&sizes[base + root], len);
 }
 
-__global__ void k_speckle_apply(int16_t* __restrict__ disp, size_t dpitch, const int* __restrict__ lab, const int* __restrict__ sizes, int w, int h,
-                                int new_val, int max_size, size_t dbs)
+__global__ void k_spk_apply(int16_t* __restrict__ disp, size_t dpitch, const int* __restrict__ lab, const int* __restrict__ rlen,
+                            const int* __restrict__ sizes, int w, int h, int new_val, int max_size, size_t dbs)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
-    size_t base = blockIdx.z * (size_t)w * h;
-    int root = lab[base + y * w + x];
-    if (root < 0) return;
+    const size_t base = blockIdx.z * (size_t)w * h;
+    const int i = y * w + x;
+    int p = lab[base + i];
+    if (p < 0) return;
+    // a start's entry holds the root (k_spk_sizes compressed it); any other pixel's entry names its run start
+    int root = rlen[base + i] > 0 ? p : lab[base + p];
     if (sizes[base + root] <= max_size) ((int16_t*)((uint8_t*)disp + blockIdx.z * dbs))[(size_t)y * dpitch + x] = (int16_t)new_val;
 }
 
@@ -307,21 +362,26 @@ int gipk_disparity_to_f32(const int16_t* disp, size_t disp_pitch, float* dst, si
     return GIP_OK;
 }
 
-size_t gipk_speckle_scratch_bytes(int w, int h, int batch) { return (size_t)w * h * batch * 8; }
+size_t gipk_speckle_scratch_bytes(int w, int h, int batch) { return (size_t)w * h * batch * 12; }
 
 int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff, void* scratch,
                          size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream)
 {
     GIPK_ARGCHECK(disp && scratch && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
     GIPK_ARGCHECK(scratch_bytes >= gipk_speckle_scratch_bytes(w, h, batch) && (size_t)w * h < (1u << 31));
+    if (w > 32768) return GIP_ERR_UNSUPPORTED;
+    const size_t n = (size_t)w * h * batch;
     int* lab = (int*)scratch;
-    int* sizes = lab + (size_t)w * h * batch;
+    int* rlen = lab + n;
+    int* sizes = rlen + n;
     hipStream_t st = (hipStream_t)stream;
     dim3 g = grid2d(w, h, batch);
-    hipLaunchKernelGGL(k_speckle_init, g, dim3(TPB), 0, st, disp, disp_pitch / 2, lab, sizes, w, h, new_val, disp_bstride);
-    hipLaunchKernelGGL(k_speckle_merge, g, dim3(TPB), 0, st, disp, disp_pitch / 2, lab, w, h, new_val, max_diff, disp_bstride);
-    hipLaunchKernelGGL(k_speckle_count, g, dim3(TPB), 0, st, lab, sizes, w, h);
-    hipLaunchKernelGGL(k_speckle_apply, g, dim3(TPB), 0, st, disp, disp_pitch / 2, lab, sizes, w, h, new_val, max_speckle_size, disp_bstride);
+    size_t sh = (((size_t)w * 2 + 2 + 15) & ~(size_t)15) + SPK_TPB * sizeof(int);
+    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_spk_runs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(k_spk_runs, dim3(h, 1, batch), dim3(SPK_TPB), sh, st, disp, disp_pitch / 2, lab, rlen, sizes, w, h, new_val, max_diff, disp_bstride);
+    hipLaunchKernelGGL(k_spk_merge, g, dim3(TPB), 0, st, disp, disp_pitch / 2, lab, w, h, new_val, max_diff, disp_bstride);
+    hipLaunchKernelGGL(k_spk_sizes, g, dim3(TPB), 0, st, lab, rlen, sizes, w, h);
+    hipLaunchKernelGGL(k_spk_apply, g, dim3(TPB), 0, st, disp, disp_pitch / 2, lab, rlen, sizes, w, h, new_val, max_speckle_size, disp_bstride);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
