@@ -1,0 +1,27 @@
+// bm_common.h -- argument block shared by the block-matching kernels (k_stereobm.hip, k_stereobm_c4.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct BmArgs {
+    const uint8_t* L;
+    const uint8_t* R;
+    size_t pitch;
+    int w, h;
+    int ndisp, mindisp, wsz2, lofs, rofs, width1;
+    int ftzero, tex_thr, uniq;
+    int row0, row1, rows_per_chunk;
+    int cbeg, cend;      // fast kernel: output columns (relative index c) [cbeg, cend)
+    int nleft, nright;   // generic kernel: c in [0,nleft) U [width1-nright, width1)
+    int TC;              // generic kernel: columns per tile
+    int16_t* disp;
+    size_t dpitch;       // elements
+    int32_t* cost;       // may be null
+    size_t cpitch;       // elements
+    size_t img_bs, disp_bs, cost_bs;  // batch strides in bytes
+    int filtered;
+};
+
+// k_stereobm_c4.hip: column-sum matcher for the interior columns.  Returns GIP_OK and sets *handled when a kernel
+// instantiation exists for (ndisp, block radius); otherwise leaves *handled false and launches nothing.
+int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled);

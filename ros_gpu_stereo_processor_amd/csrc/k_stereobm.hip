@@ -21,6 +21,7 @@
 //   matter to the L/R check, and as the fallback).
 // u16 sums require 2*cap*block^2 < 65536 (cap 31 -> block <= 31; cap 63 -> block <= 21).
 #include "gip_internal.h"
+#include "bm_common.h"
 
 // set by gip_batch_run (gip_capi.hip) to time the dominant kernel on its own stream
 extern thread_local hipEvent_t g_bm_ev0, g_bm_ev1;
@@ -30,24 +31,6 @@ namespace {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-struct BmArgs {
-    const uint8_t* L;
-    const uint8_t* R;
-    size_t pitch;
-    int w, h;
-    int ndisp, mindisp, wsz2, lofs, rofs, width1;
-    int ftzero, tex_thr, uniq;
-    int row0, row1, rows_per_chunk;
-    int cbeg, cend;      // fast kernel: output columns (relative index c) [cbeg, cend)
-    int nleft, nright;   // generic kernel: c in [0,nleft) U [width1-nright, width1)
-    int TC;              // generic kernel: columns per tile
-    int16_t* disp;
-    size_t dpitch;       // elements
-    int32_t* cost;       // may be null
-    size_t cpitch;       // elements
-    size_t img_bs, disp_bs, cost_bs;  // batch strides in bytes
-    int filtered;
-};
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ u32 umin(u32 a, u32 b) { return a < b ? a : b; }
@@ -504,7 +487,17 @@ extern "C" int gipk_bm_match(const uint8_t* left, const uint8_t* right, size_t p
 
     // border columns matter only to validateDisparity (they are blanked afterwards)
     const bool need_border = p->disp12_max_diff >= 0;
-    if (fast_ok) {
+    bool c4_done = false;
+    if (cend > cbeg) {
+        // preferred: column-sum matcher (k_stereobm_c4.hip) when an instantiation exists for (ndisp, block)
+        a.cbeg = cbeg; a.cend = cend;
+        rc = gip_bm_c4_launch(a, batch, st, &c4_done);
+        if (rc != GIP_OK) return rc;
+    }
+    if (c4_done) {
+        a.nleft = need_border ? (r < g.width1 ? r : g.width1) : 0;
+        a.nright = need_border ? r : 0;
+    } else if (fast_ok) {
         a.cbeg = cbeg; a.cend = cend;
         int ntiles = gip_div_up(cend - cbeg, 64);
         int nch = pick_chunks(ntiles);

@@ -1,0 +1,388 @@
+// k_stereobm_c4.hip -- the main SAD block matcher for gfx950 ("column-sum" form), interior columns.
+//
+// Same semantics as k_stereobm.hip (cv::StereoBM, reference src/GPUStereoProcessor.cpp:312-321); different work mapping,
+// built around what the packed-byte SAD unit and the DPP cross-lane network of a CDNA4 wavefront do well:
+//
+//   * ONE WAVEFRONT = ONE WORKGROUP = one tile of 64 image columns x all disparities, marching down its row chunk.
+//     lane = s*16 + t :  t in [0,16) owns the 4 adjacent columns 4t..4t+3,  s in [0,4) owns a quarter of the disparity range
+//     (NG groups of 4 disparities).  No workgroup barrier exists on the hot path (a single wave needs none).
+//   * Per (column, 4 disparities) the lane keeps the VERTICAL running column sum  V' = sum over the 2r+1 window rows of
+//     |L - R|  as 4 packed u16 in a 64-bit register pair.  A row entering the window is added by one v_mqsad_pk_u16_u8
+//     whose reference dword holds the single left byte (the other three bytes are zero = masked; pixels are biased by +1 so a
+//     real pixel is never zero); the four columns of a lane share the SAME 8-byte right-image window -- column q just puts
+//     its byte at position q -- so all operands are plain aligned LDS dwords, no byte shuffling.  The row leaving the window
+//     is recomputed the same way and subtracted with two 32-bit subtracts (no borrow can cross the packed lanes).
+//   * The HORIZONTAL window sum is formed across lanes with DPP row shifts inside the 16-lane row that holds one disparity
+//     quarter: in-lane prefix sums P1..P4 of the 4 columns, then  H_q = sum over neighbour lanes of (P[hi+1] - P[lo]).
+//     Outputs are valid for lanes t in [K, 15-K], K = ceil(r/4); tiles advance by 64-8K columns.
+//   * Winner-take-all: per 4-disparity group a packed min and one 32-bit key (cost << 8 | group); quarters are merged with
+//     two xor-shuffles.  The row's cost slice is parked in LDS; lane (s,t) then finalises pixel 4t+s: exact winner inside the
+//     group, sub-pixel neighbours, texture test and the uniqueness test (count of groups <= threshold vs the groups that
+//     touch the winner, then an exact check of those 12 costs).
+//   * Prefiltered rows are staged in an LDS ring of 2r+1 rows by the wave itself with aligned dword loads issued one row
+//     ahead (register prefetch), so global latency overlaps the SAD work.
+#include "gip_internal.h"
+#include "bm_common.h"
+
+#include <type_traits>
+#include <utility>
+
+extern thread_local hipEvent_t g_bm_ev0, g_bm_ev1;
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ u32 umin(u32 a, u32 b) { return a < b ? a : b; }
+
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    us2 x = __builtin_bit_cast(us2, a), y = __builtin_bit_cast(us2, b);
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(x, y));
+}
+
+// value of lane (t + D) within the 16-lane DPP row; lanes without a source get 0
+template <int D>
+__device__ __forceinline__ u32 lane_at(u32 v)
+{
+    if constexpr (D == 0) return v;
+    else if constexpr (D < 0) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + (-D), 0xF, 0xF, true);  // row_shr:-D
+    else return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + D, 0xF, 0xF, true);                           // row_shl:D
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// packed pair (two dwords = 4 x u16) helpers
+struct P2 { u32 lo, hi; };
+__device__ __forceinline__ P2 operator+(P2 a, P2 b) { return {a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi - b.hi}; }
+
+// Horizontal window sum for output column q of this lane from the in-lane prefix sums P[0..4] (P[0] = 0) of every lane:
+//   window = columns [4t+q-R, 4t+q+R];  lane t+d covers columns 4(t+d)..4(t+d)+3  ->  sub-columns [lo,hi]
+template <int R, int Q, class T, class SHIFT>
+__device__ __forceinline__ T hsum(const T (&P)[5], SHIFT&& shift)
+{
+    constexpr int K = (R + 3) / 4;
+    T acc{};
+    static_for<0, 2 * K + 1>([&](auto iv) {
+        constexpr int d = decltype(iv)::value - K;
+        constexpr int lo = (Q - R - 4 * d) > 0 ? (Q - R - 4 * d) : 0;
+        constexpr int hi = (Q + R - 4 * d) < 3 ? (Q + R - 4 * d) : 3;
+        if constexpr (lo <= hi) {
+            if constexpr (lo == 0) acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1]);
+            else acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1] - P[lo]);
+        }
+    });
+    return acc;
+}
+
+struct C4Smem {
+    // ring slot: [L row: 64 bytes][R row: rwb bytes]; then the cost slice 64 x cspb
+    int slotb, rwb, cspb;
+};
+
+template <int NG, int R>
+__global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
+{
+    constexpr int K = (R + 3) / 4;
+    constexpr int NRING = 2 * R + 1;
+    constexpr int NDISP = 16 * NG;
+    constexpr int RWD = 17 + 4 * NG;            // right-row dwords needed per ring slot
+    constexpr int RWDP = (RWD + 3) & ~3;        // padded to 16 bytes
+    constexpr int SLOTD = 16 + RWDP;            // dwords per ring slot
+    constexpr int CSPB = 2 * NDISP + 16;        // bytes per column of the cost slice
+    constexpr int NLD = (RWD + 63) / 64;        // right-row dwords each lane stages per row (1 or 2)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    u32* ring = (u32*)smem_raw;
+    uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
+
+    const int lane = threadIdx.x, t = lane & 15, s = lane >> 4;
+    const int c0 = a.cbeg - 4 * K + blockIdx.x * (64 - 8 * K);   // relative column of lane t=0, q=0
+    const int ya = a.row0 + blockIdx.y * a.rows_per_chunk;
+    const int yb = min(ya + a.rows_per_chunk, a.row1);
+    if (ya >= yb) return;
+
+    const uint8_t* Lb = a.L + blockIdx.z * a.img_bs;
+    const uint8_t* Rb = a.R + blockIdx.z * a.img_bs;
+    int16_t* disp = (int16_t*)((uint8_t*)a.disp + blockIdx.z * a.disp_bs);
+    int32_t* cost = a.cost ? (int32_t*)((uint8_t*)a.cost + blockIdx.z * a.cost_bs) : nullptr;
+
+    // ---- row staging: aligned dword loads + funnel shift, clamped to the row's dword range (pitch % 4 == 0)
+    const int lcol0 = a.lofs + c0;   // absolute column of L ring byte 0
+    const int rcol0 = a.rofs + c0;   // absolute column of R ring byte 0
+    const int ndw = (int)(a.pitch >> 2);
+    const int lsh = lcol0 & 3, rsh = rcol0 & 3;
+    const int ldw = (lcol0 >> 2) + lane;  // (arithmetic shift: floor for negative columns)
+    const int rdw = (rcol0 >> 2) + lane;
+    auto fetch = [&](const uint8_t* base, int yy, int dw, int sh) -> u32 {
+        const u32* row = (const u32*)(base + (size_t)yy * a.pitch);
+        u32 lo = row[clampi(dw, 0, ndw - 1)], hi = row[clampi(dw + 1, 0, ndw - 1)];
+        u32 v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        return (v & 0x7F7F7F7Fu) + 0x01010101u;   // +1 bias (valid pixels are <= 2*cap <= 126)
+    };
+    u32 pf_l = 0, pf_r[NLD];
+    auto prefetch = [&](int yy) {
+        if (lane < 16) pf_l = fetch(Lb, yy, ldw, lsh);
+#pragma unroll
+        for (int i = 0; i < NLD; i++)
+            if (lane + 64 * i < RWD) pf_r[i] = fetch(Rb, yy, rdw + 64 * i, rsh);
+    };
+    auto commit = [&](int yy) {
+        u32* slot = ring + (yy % NRING) * SLOTD;
+        if (lane < 16) slot[lane] = pf_l;
+#pragma unroll
+        for (int i = 0; i < NLD; i++)
+            if (lane + 64 * i < RWD) slot[16 + lane + 64 * i] = pf_r[i];
+    };
+
+    // ---- state
+    u32 Vlo[4][NG], Vhi[4][NG];   // vertical column sums, 4 x u16 per (column q, group g)
+    u32 TV[4];                    // vertical column sums of |L - ftzero|
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        TV[q] = 0;
+#pragma unroll
+        for (int g = 0; g < NG; g++) { Vlo[q][g] = 0; Vhi[q][g] = 0; }
+    }
+    const u32 ft1 = (u32)(a.ftzero + 1);
+
+    auto add_row = [&](int yy) {
+        const u32* slot = ring + (yy % NRING) * SLOTD;
+        const u32 lw = slot[t];
+        const u32* rw = slot + 16 + t + NG * s;
+        u32 rd[NG + 1];
+#pragma unroll
+        for (int i = 0; i <= NG; i++) rd[i] = rw[i];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 ref = lw & (0xFFu << (8 * q));
+            TV[q] = __builtin_amdgcn_sad_u8(ref, ft1 << (8 * q), TV[q]);
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                u64 acc = ((u64)Vhi[q][g] << 32) | Vlo[q][g];
+                acc = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, acc);
+                Vlo[q][g] = (u32)acc;
+                Vhi[q][g] = (u32)(acc >> 32);
+            }
+        }
+    };
+    auto sub_row = [&](int yy) {
+        const u32* slot = ring + (yy % NRING) * SLOTD;
+        const u32 lw = slot[t];
+        const u32* rw = slot + 16 + t + NG * s;
+        u32 rd[NG + 1];
+#pragma unroll
+        for (int i = 0; i <= NG; i++) rd[i] = rw[i];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 ref = lw & (0xFFu << (8 * q));
+            TV[q] -= __builtin_amdgcn_sad_u8(ref, ft1 << (8 * q), 0u);
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                u64 tq = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, 0ull);
+                Vlo[q][g] -= (u32)tq;           // lane-wise V >= t: no borrow crosses the packed halves
+                Vhi[q][g] -= (u32)(tq >> 32);
+            }
+        }
+    };
+
+    // ---- warm-up: rows ya-R .. ya+R-1 enter the window
+    for (int yy = ya - R; yy < ya + R; yy++) {
+        prefetch(yy);
+        commit(yy);
+    }
+    __syncthreads();
+    for (int yy = ya - R; yy < ya + R; yy++) add_row(yy);
+    prefetch(ya + R);
+
+    const int my_col = 4 * t + s;                 // the tile column this lane finalises
+    const int c_out = c0 + my_col;
+    const bool writer = (t >= K) && (t <= 15 - K) && (c_out >= a.cbeg) && (c_out < a.cend);
+    uint8_t* csrow_w = cs + (size_t)(4 * t) * CSPB + (size_t)(4 * NG * s) * 2;   // where this lane parks (column 4t+q, its groups)
+    const uint8_t* csrow_r = cs + (size_t)my_col * CSPB;
+
+    for (int y = ya; y < yb; y++) {
+        __syncthreads();          // single wave: orders the LDS traffic of the previous iteration before the slot is reused
+        commit(y + R);
+        __syncthreads();
+        if (y + R + 1 < a.h) prefetch(y + R + 1);
+        add_row(y + R);
+
+        // ---- horizontal window sums, group keys, cost slice
+        u32 best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        u32 gmin[4][NG];          // min cost of each group (for the uniqueness count)
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            P2 P[5];
+            P[0] = {0u, 0u};
+            P[1] = {Vlo[0][g], Vhi[0][g]};
+            P[2] = P[1] + P2{Vlo[1][g], Vhi[1][g]};
+            P[3] = P[2] + P2{Vlo[2][g], Vhi[2][g]};
+            P[4] = P[3] + P2{Vlo[3][g], Vhi[3][g]};
+            auto shift = [](auto dv, P2 v) -> P2 {
+                constexpr int d = decltype(dv)::value;
+                return P2{lane_at<d>(v.lo), lane_at<d>(v.hi)};
+            };
+            static_for<0, 4>([&](auto qv) {
+                constexpr int q = decltype(qv)::value;
+                const P2 H = hsum<R, q>(P, shift);
+                u32 m = pk_min_u16(H.lo, H.hi);
+                u32 gm = umin(m & 0xFFFFu, m >> 16);
+                gmin[q][g] = gm;
+                best[q] = umin(best[q], (gm << 8) | (u32)(NG * s + g));
+                *(uint2*)(csrow_w + (size_t)q * CSPB + g * 8) = make_uint2(H.lo, H.hi);
+            });
+        }
+        // texture sums (32-bit, same window)
+        u32 tsum_q[4];
+        {
+            u32 P[5];
+            P[0] = 0; P[1] = TV[0]; P[2] = P[1] + TV[1]; P[3] = P[2] + TV[2]; P[4] = P[3] + TV[3];
+            auto shift = [](auto dv, u32 v) -> u32 { return lane_at<decltype(dv)::value>(v); };
+            static_for<0, 4>([&](auto qv) { constexpr int q = decltype(qv)::value; tsum_q[q] = hsum<R, q>(P, shift); });
+        }
+        // merge the four disparity quarters (lanes t, t+16, t+32, t+48)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 16));
+            best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 32));
+        }
+        __syncthreads();          // cost slice complete (single wave)
+
+        // uniqueness: groups whose minimum is <= the per-column threshold, summed over the quarters
+        u32 cnt[4] = {0, 0, 0, 0};
+        if (a.uniq > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 ms = best[q] >> 8;
+                const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
+#pragma unroll
+                for (int g = 0; g < NG; g++) cnt[q] += (gmin[q][g] <= thr) ? 1u : 0u;
+                cnt[q] += (u32)__shfl_xor((int)cnt[q], 16);
+                cnt[q] += (u32)__shfl_xor((int)cnt[q], 32);
+            }
+        }
+        // ---- finalise pixel (column 4t+s) in this lane
+        const u32 key = s == 0 ? best[0] : s == 1 ? best[1] : s == 2 ? best[2] : best[3];
+        const int tsum = (int)(s == 0 ? tsum_q[0] : s == 1 ? tsum_q[1] : s == 2 ? tsum_q[2] : tsum_q[3]);
+        const int ngle = (int)(s == 0 ? cnt[0] : s == 1 ? cnt[1] : s == 2 ? cnt[2] : cnt[3]);
+        const int minsad = (int)(key >> 8), gstar = (int)(key & 0xFFu);
+        const unsigned short* csw = (const unsigned short*)csrow_r;
+        int d_out = a.filtered;
+        {
+            const uint2 grp = *(const uint2*)(csrow_r + gstar * 8);
+            const int c0v = grp.x & 0xFFFF, c1v = grp.x >> 16, c2v = grp.y & 0xFFFF;
+            const int k = (c0v == minsad) ? 0 : (c1v == minsad) ? 1 : (c2v == minsad) ? 2 : 3;   // first minimum
+            const int mind = 4 * gstar + k;
+            bool ok = tsum >= a.tex_thr;
+            if (a.uniq > 0 && ok) {
+                const int thr = minsad + (minsad * a.uniq) / 100;
+                // groups that can hold the winner's neighbours: gstar-1 .. gstar+1
+                int touch_le = 0;
+                bool viol = false;
+#pragma unroll
+                for (int dg = -1; dg <= 1; dg++) {
+                    const int gg = gstar + dg;
+                    if (gg < 0 || gg >= 4 * NG) continue;
+                    const uint2 v = *(const uint2*)(csrow_r + gg * 8);
+                    const int cc[4] = {(int)(v.x & 0xFFFF), (int)(v.x >> 16), (int)(v.y & 0xFFFF), (int)(v.y >> 16)};
+                    bool any_le = false;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int d = 4 * gg + j;
+                        const bool le = cc[j] <= thr;
+                        any_le |= le;
+                        viol |= le && (d < mind - 1 || d > mind + 1);
+                    }
+                    touch_le += any_le ? 1 : 0;
+                }
+                // a group that does not touch the winner lies entirely outside [mind-1, mind+1]
+                ok = !viol && (ngle <= touch_le);
+            }
+            if (ok) {
+                const int ip = (mind + 1 == NDISP) ? NDISP - 2 : mind + 1;
+                const int in = (mind == 0) ? 1 : mind - 1;
+                const int p = csw[ip], n = csw[in];
+                const int den = p + n - 2 * minsad + (p > n ? p - n : n - p);
+                const int v = (NDISP - mind - 1 + a.mindisp) * 256 + (den != 0 ? (p - n) * 256 / den : 0) + 15;
+                d_out = v >> 4;
+            }
+        }
+        if (writer) {
+            disp[(size_t)y * a.dpitch + a.lofs + c_out] = (int16_t)d_out;
+            if (cost) cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
+        }
+        sub_row(y - R);
+    }
+}
+
+template <int NG, int R>
+int launch_c4(const BmArgs& a, int batch, hipStream_t st)
+{
+    constexpr int K = (R + 3) / 4;
+    constexpr int RWD = 17 + 4 * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
+    const size_t sh = (size_t)(2 * R + 1) * SLOTD * 4 + (size_t)64 * (2 * 16 * NG + 16);
+    const int ncols = a.cend - a.cbeg;
+    const int ntiles = (ncols + (64 - 8 * K) - 1) / (64 - 8 * K);
+    const int nrows = a.row1 - a.row0;
+    // row chunks: fill the chip (~2048 waves at 8 per CU) while keeping the 2R-row warm-up small
+    int want = (4096 + ntiles * batch - 1) / (ntiles * batch);
+    int maxchunks = nrows / (6 * R + 6);
+    if (maxchunks < 1) maxchunks = 1;
+    int nch = want < 1 ? 1 : (want > maxchunks ? maxchunks : want);
+    BmArgs b = a;
+    b.rows_per_chunk = (nrows + nch - 1) / nch;
+    nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;
+    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (g_bm_ev0) GIP_HIP_CHECK(hipEventRecord(g_bm_ev0, st));
+    hipLaunchKernelGGL((k_bm_c4<NG, R>), dim3(ntiles, nch, batch), dim3(64), sh, st, b);
+    GIP_LAUNCH_CHECK();
+    if (g_bm_ev1) GIP_HIP_CHECK(hipEventRecord(g_bm_ev1, st));
+    return GIP_OK;
+}
+
+template <int NG>
+int dispatch_r(const BmArgs& a, int batch, hipStream_t st, bool* handled)
+{
+    *handled = true;
+    switch (a.wsz2) {
+    case 2: return launch_c4<NG, 2>(a, batch, st);
+    case 3: return launch_c4<NG, 3>(a, batch, st);
+    case 4: return launch_c4<NG, 4>(a, batch, st);
+    case 5: return launch_c4<NG, 5>(a, batch, st);
+    case 7: return launch_c4<NG, 7>(a, batch, st);
+    case 10: return launch_c4<NG, 10>(a, batch, st);
+    default: *handled = false; return GIP_OK;
+    }
+}
+
+}  // namespace
+
+int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled)
+{
+    *handled = false;
+    // aligned dword staging needs 4-byte aligned rows
+    if ((a.pitch & 3) || ((uintptr_t)a.L & 3) || ((uintptr_t)a.R & 3) || (a.img_bs & 3)) return GIP_OK;
+    if (a.cend <= a.cbeg) return GIP_OK;
+    switch (a.ndisp) {
+    case 16: return dispatch_r<1>(a, batch, st, handled);
+    case 32: return dispatch_r<2>(a, batch, st, handled);
+    case 48: return dispatch_r<3>(a, batch, st, handled);
+    case 64: return dispatch_r<4>(a, batch, st, handled);
+    case 96: return dispatch_r<6>(a, batch, st, handled);
+    case 128: return dispatch_r<8>(a, batch, st, handled);
+    case 192: return dispatch_r<12>(a, batch, st, handled);
+    case 256: return dispatch_r<16>(a, batch, st, handled);
+    default: return GIP_OK;
+    }
+}
