@@ -307,6 +307,11 @@ int gipk_pack_pointcloud2(const float *xyz, size_t xyz_pitch, const uint8_t *bgr
 int gipk_disparity_to_pointcloud2(const int16_t *disp, size_t disp_pitch, const uint8_t *bgr, size_t bgr_pitch, uint8_t *out,
                                   int w, int h, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
                                   size_t disp_bstride, size_t bgr_bstride, size_t out_bstride, gip_stream stream);
+/* fused tail of the chain: int16 disparity -> float image (f32_out, contiguous, may be NULL) and/or PointCloud2 records
+ * (pc_out, contiguous batch*h*w*32 bytes, may be NULL); color_cn = 1 (mono, replicated like GRAY2BGR) or 3 (BGR) */
+int gipk_disparity_outputs(const int16_t *disp, size_t disp_pitch, const uint8_t *color, size_t color_pitch, int color_cn, float *f32_out,
+                           uint8_t *pc_out, int w, int h, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
+                           size_t disp_bstride, size_t color_bstride, gip_stream stream);
 int gipk_draw_color_disp(const int16_t *disp, size_t disp_pitch, uint8_t *bgra, size_t bgra_pitch, int w, int h, int ndisp,
                          int batch, size_t disp_bstride, size_t bgra_bstride, gip_stream stream);
 

@@ -161,6 +161,7 @@ PROTOTYPES = {
     "gipk_reproject_to_3d": (_i, [_vp, _sz, _vp, _sz, _i, _i, C.POINTER(_d), C.c_float, _i, _i, _sz, _sz, _vp]),
     "gipk_pack_pointcloud2": (_i, [_vp, _sz, _vp, _sz, _vp, _i, _i, _i, _sz, _sz, _sz, _vp]),
     "gipk_disparity_to_pointcloud2": (_i, [_vp, _sz, _vp, _sz, _vp, _i, _i, C.POINTER(_d), _d, _d, _i, _i, _sz, _sz, _sz, _vp]),
+    "gipk_disparity_outputs": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp, _i, _i, C.POINTER(_d), _d, _d, _i, _i, _sz, _sz, _vp]),
     "gipk_draw_color_disp": (_i, [_vp, _sz, _vp, _sz, _i, _i, _i, _i, _sz, _sz, _vp]),
     "gip_batch_set_maps_device": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "gip_batch_run": (_i, [_vp, C.POINTER(BatchDesc), _vp]),

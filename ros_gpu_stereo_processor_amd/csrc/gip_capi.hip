@@ -1091,18 +1091,21 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
             H_HIP(h, hipMemcpyAsync(h->b_rect[i].p, mono[i], npx * B, hipMemcpyDeviceToDevice, st));
     }
     const uint8_t* rect_color = nullptr;
+    int rect_color_cn = 3;
     if (want_pc) {
-        B_STEP(ensure_dev(h, h->b_rect_color, npx * 3 * B), "batch buffers");
         if (color_l) {
+            B_STEP(ensure_dev(h, h->b_rect_color, npx * 3 * B), "batch buffers");
             if (h->model.left.distorted)
                 B_STEP(gipk_remap_u8(color_l, (size_t)w * 3, w, hh, (uint8_t*)h->b_rect_color.p, (size_t)w * 3, w, hh, 3, h->d_map1[0], h->d_map2[0], B, npx * 3, npx * 3, st), "rectify colour");
             else
                 H_HIP(h, hipMemcpyAsync(h->b_rect_color.p, color_l, npx * 3 * B, hipMemcpyDeviceToDevice, st));
+            rect_color = (const uint8_t*)h->b_rect_color.p;
         } else {
-            // mono8 input: GRAY2BGR then remap == remap then GRAY2BGR (every channel sees the same taps and weights)
-            B_STEP(gipk_cvt_gray_to_bgr((const uint8_t*)h->b_rect[0].p, w, (uint8_t*)h->b_rect_color.p, (size_t)w * 3, w, hh, B, npx, npx * 3, st), "gray->bgr");
+            // mono8 input: GRAY2BGR then remap == remap then GRAY2BGR (every channel sees the same taps and weights), and the
+            // replication itself is folded into the cloud kernel (colour channels = 1)
+            rect_color = (const uint8_t*)h->b_rect[0].p;
+            rect_color_cn = 1;
         }
-        rect_color = (const uint8_t*)h->b_rect_color.p;
     }
     // stage 3: disparity + speckle (StereoProcessor.cpp:259-268)
     B_STEP(ensure_dev(h, h->bm_scratch, gipk_stereobm_scratch_bytes(w, hh, B, &bp)), "batch buffers");
@@ -1117,12 +1120,10 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         B_STEP(gipk_filter_speckles(d->disparity, (size_t)w * 2, w, hh, (bp.min_disparity - 1) * 16, h->max_speckle_size, (int)(h->max_speckle_diff * 16.0), h->spk_scratch.p,
                                     h->spk_scratch.cap, B, npx * 2, st), "speckle");
     }
-    if (d->disparity_f32)
-        B_STEP(gipk_disparity_to_f32(d->disparity, (size_t)w * 2, d->disparity_f32, (size_t)w * 4, w, hh, h->model.left.cx(), h->model.right.cx(), B, npx * 2, npx * 4, st), "disparity->f32");
-    // stage 5: cloud (StereoProcessor.cpp:278-282 + GpuSenderPc2.cpp)
-    if (want_pc)
-        B_STEP(gipk_disparity_to_pointcloud2(d->disparity, (size_t)w * 2, rect_color, (size_t)w * 3, d->pointcloud, w, hh, h->model.Q, h->model.left.cx(), h->model.right.cx(),
-                                             bp.min_disparity, B, npx * 2, npx * 3, npx * 32, st), "pointcloud");
+    // stage 5: float disparity (GPUStereoProcessor.cpp:320) + cloud (StereoProcessor.cpp:278-282, GpuSenderPc2.cpp) in one pass
+    if (d->disparity_f32 || want_pc)
+        B_STEP(gipk_disparity_outputs(d->disparity, (size_t)w * 2, rect_color, (size_t)w * rect_color_cn, rect_color_cn, d->disparity_f32, want_pc ? d->pointcloud : nullptr, w, hh,
+                                      h->model.Q, h->model.left.cx(), h->model.right.cx(), bp.min_disparity, B, npx * 2, npx * rect_color_cn, st), "disparity outputs");
     H_HIP(h, hipEventRecord(ev[3], st));
     h->timing_runs++;
 #undef B_STEP

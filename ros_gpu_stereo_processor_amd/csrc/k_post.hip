@@ -24,7 +24,7 @@ constexpr int TPB = 256;
 // (cost << 32 | x << 16 | d) reduced with an LDS atomic min: lowest cost wins, ties go to the smallest x --
 // exactly the strict '>' replacement rule of the sequential scan.
 __global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const int32_t* cost, size_t cpitch, int w, int h, int mindisp, int ndisp,
-                              int disp12, int roi_x, int roi_y, int roi_w, int roi_h, size_t dbs, size_t cbs)
+                              int disp12, int roi_x, int roi_y, int roi_w, int roi_h, int wr0, int wr1, size_t dbs, size_t cbs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     u64* keys = (u64*)smem_raw;
@@ -68,9 +68,10 @@ __global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const int32_t* cost,
             if (bad0 && bad1) dptr[x] = (int16_t)INVALID;
         }
     }
-    // blank everything outside the valid ROI columns (after the L/R check, as OpenCV does)
+    // blank everything outside the valid ROI columns (after the L/R check, as OpenCV does) and the columns the matcher
+    // never writes ([wr0, wr1) = [lofs, lofs + width1) is its output range)
     for (int x = threadIdx.x; x < w; x += blockDim.x)
-        if (x < roi_x || x >= roi_x + roi_w) dptr[x] = (int16_t)INVALID;
+        if (x < roi_x || x >= roi_x + roi_w || x < wr0 || x >= wr1) dptr[x] = (int16_t)INVALID;
 }
 
 __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, float* __restrict__ dst, size_t fpitch, int w, int h, float alpha,
@@ -277,10 +278,13 @@ __global__ void k_pack_pc2(const float* __restrict__ xyz, size_t xpitch, const u
     store_pc2_record(out + blockIdx.z * obs + ((size_t)y * w + x) * 32, p[0], p[1], p[2], col);
 }
 
-// fused: int16 x16 disparity -> float (d/16 - (cx_l-cx_r)) -> reproject -> 32-byte record.  Missing = FILTERED, which is
-// always the image minimum of a StereoBM map (rows 0..r-1 are FILTERED and every valid value is >= mindisp*16).
-__global__ void k_disp_to_pc2(const int16_t* __restrict__ disp, size_t dpitch, const uint8_t* __restrict__ bgr, size_t bpitch,
-                              uint8_t* __restrict__ out, int w, int h, QMat Q, float alpha, float beta, int filtered, size_t dbs, size_t bbs, size_t obs)
+// fused: int16 x16 disparity -> float (d/16 - (cx_l-cx_r)) [optionally stored] -> reproject -> 32-byte record.
+// Missing = FILTERED, which is always the image minimum of a StereoBM map (rows 0..r-1 are FILTERED and every valid value
+// is >= mindisp*16).  CN = channels of the colour image (1: mono replicated = GRAY2BGR, 3: BGR).
+template <int CN>
+__global__ void k_disp_outputs(const int16_t* __restrict__ disp, size_t dpitch, const uint8_t* __restrict__ col, size_t cpitch,
+                               float* __restrict__ f32out, uint8_t* __restrict__ pc, int w, int h, QMat Q, float alpha, float beta, int filtered,
+                               size_t dbs, size_t cbs, size_t fbs, size_t obs)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
@@ -288,18 +292,21 @@ __global__ void k_disp_to_pc2(const int16_t* __restrict__ disp, size_t dpitch, c
     int d16 = ((const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs))[(size_t)y * dpitch + x];
     float df = (float)d16 * alpha;
     df = df + beta;
+    if (f32out) ((float*)((uint8_t*)f32out + blockIdx.z * fbs))[(size_t)y * w + x] = df;
+    if (!pc) return;
     double d = df;
     double qx = q[1] * y + q[3] + q[0] * x, qy = q[5] * y + q[7] + q[4] * x;
     double qz = q[9] * y + q[11] + q[8] * x, qw = q[13] * y + q[15] + q[12] * x;
     double iW = 1. / (qw + q[14] * d);
     double X = (qx + q[2] * d) * iW, Y = (qy + q[6] * d) * iW, Z = (qz + q[10] * d) * iW;
     if (d16 == filtered) Z = 10000.;
-    u32 col = 0;
-    if (bgr) {
-        const uint8_t* c = bgr + blockIdx.z * bbs + (size_t)y * bpitch + 3 * (size_t)x;
-        col = (u32)c[0] | ((u32)c[1] << 8) | ((u32)c[2] << 16);
+    u32 c = 0;
+    if (col) {
+        const uint8_t* cp = col + blockIdx.z * cbs + (size_t)y * cpitch + (size_t)CN * x;
+        if (CN == 1) c = (u32)cp[0] * 0x010101u;
+        else c = (u32)cp[0] | ((u32)cp[1] << 8) | ((u32)cp[2] << 16);
     }
-    store_pc2_record(out + blockIdx.z * obs + ((size_t)y * w + x) * 32, (float)X, (float)Y, (float)Z, col);
+    store_pc2_record(pc + blockIdx.z * obs + ((size_t)y * w + x) * 32, (float)X, (float)Y, (float)Z, c);
 }
 
 // cv::cuda::drawColorDisp: HSV ramp (S = V = 1) of the integer disparity; invalid (< 0) -> 0
@@ -347,7 +354,8 @@ int gipk_bm_finalize(int16_t* disp, size_t disp_pitch, const int32_t* cost, size
     int rx = g.roi_x, ry = g.roi_y, rw = g.roi_w, rh = g.roi_h;
     if (g.degenerate) { rx = ry = rw = rh = 0; }
     hipLaunchKernelGGL(k_bm_finalize, dim3(h, 1, batch), dim3(TPB), sh, (hipStream_t)stream, disp, disp_pitch / 2, cost, cost ? cost_pitch / 4 : 0, w, h,
-                       p->min_disparity, p->num_disparities, g.degenerate ? -1 : p->disp12_max_diff, rx, ry, rw, rh, disp_bstride, cost_bstride);
+                       p->min_disparity, p->num_disparities, g.degenerate ? -1 : p->disp12_max_diff, rx, ry, rw, rh, g.lofs, g.lofs + g.width1, disp_bstride,
+                       cost_bstride);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
@@ -408,17 +416,33 @@ int gipk_pack_pointcloud2(const float* xyz, size_t xyz_pitch, const uint8_t* bgr
     return GIP_OK;
 }
 
+int gipk_disparity_outputs(const int16_t* disp, size_t disp_pitch, const uint8_t* color, size_t color_pitch, int color_cn, float* f32_out,
+                           uint8_t* pc_out, int w, int h, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
+                           size_t disp_bstride, size_t color_bstride, gip_stream stream)
+{
+    GIPK_ARGCHECK(disp && Q && (f32_out || pc_out) && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
+    GIPK_ARGCHECK(!pc_out || ((uintptr_t)pc_out & 15) == 0);
+    GIPK_ARGCHECK(!color || color_cn == 1 || color_cn == 3);
+    QMat q;
+    for (int i = 0; i < 16; i++) q.q[i] = Q[i];
+    const float alpha = (float)(1.0 / 16), beta = (float)(-(cx_l - cx_r));
+    const size_t npx = (size_t)w * h;
+    if (color && color_cn == 1)
+        hipLaunchKernelGGL(k_disp_outputs<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q,
+                           alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32);
+    else
+        hipLaunchKernelGGL(k_disp_outputs<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q,
+                           alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
 int gipk_disparity_to_pointcloud2(const int16_t* disp, size_t disp_pitch, const uint8_t* bgr, size_t bgr_pitch, uint8_t* out, int w, int h,
                                   const double Q[16], double cx_l, double cx_r, int min_disparity, int batch, size_t disp_bstride, size_t bgr_bstride,
                                   size_t out_bstride, gip_stream stream)
 {
-    GIPK_ARGCHECK(disp && out && Q && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0 && ((uintptr_t)out & 15) == 0 && out_bstride % 16 == 0);
-    QMat q;
-    for (int i = 0; i < 16; i++) q.q[i] = Q[i];
-    hipLaunchKernelGGL(k_disp_to_pc2, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, bgr, bgr_pitch, out, w, h, q,
-                       (float)(1.0 / 16), (float)(-(cx_l - cx_r)), (min_disparity - 1) * 16, disp_bstride, bgr_bstride, out_bstride);
-    GIP_LAUNCH_CHECK();
-    return GIP_OK;
+    GIPK_ARGCHECK(out && out_bstride == (size_t)w * h * 32);
+    return gipk_disparity_outputs(disp, disp_pitch, bgr, bgr_pitch, 3, nullptr, out, w, h, Q, cx_l, cx_r, min_disparity, batch, disp_bstride, bgr_bstride, stream);
 }
 
 int gipk_draw_color_disp(const int16_t* disp, size_t disp_pitch, uint8_t* bgra, size_t bgra_pitch, int w, int h, int ndisp, int batch,
@@ -461,7 +485,7 @@ int gipk_stereobm(const uint8_t* left, const uint8_t* right, size_t pitch, int w
     rc = gipk_prefilter(right, pitch, rf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
     if (rc != GIP_OK) return rc;
     const bool lr = p->disp12_max_diff >= 0;
-    rc = gipk_bm_match(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream);
+    rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true);
     if (rc != GIP_OK) return rc;
     rc = gipk_bm_finalize(disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, w, h, p, batch, disp_bstride, (size_t)w * h * 4, stream);
     if (rc != GIP_OK) return rc;

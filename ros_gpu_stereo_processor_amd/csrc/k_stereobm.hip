@@ -445,6 +445,14 @@ extern "C" int gipk_bm_match(const uint8_t* left, const uint8_t* right, size_t p
                              size_t disp_pitch, int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride,
                              size_t cost_bstride, gip_stream stream)
 {
+    return gip_bm_match_impl(left, right, pitch, w, h, p, disp, disp_pitch, cost, cost_pitch, batch, img_bstride, disp_bstride, cost_bstride, stream, false);
+}
+
+// skip_fill: the caller runs gipk_bm_finalize afterwards, which blanks every pixel the matcher does not write
+int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
+                      int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride, size_t cost_bstride, gip_stream stream,
+                      bool skip_fill)
+{
     if (!left || !right || !disp || w <= 0 || h <= 0 || batch <= 0) return GIP_ERR_INVALID_ARG;
     if (disp_pitch % 2 || (cost && cost_pitch % 4)) return GIP_ERR_INVALID_ARG;
     int rc = gip_validate_bm_params(p, w, h);
@@ -454,8 +462,10 @@ extern "C" int gipk_bm_match(const uint8_t* left, const uint8_t* right, size_t p
     // u16 window sums: 2*cap*block^2 must stay below 65536 (also keeps the poison value 0xFFFF unreachable)
     if ((long)2 * p->prefilter_cap * p->block_size * p->block_size >= 65535 || p->num_disparities > 4096) return GIP_ERR_UNSUPPORTED;
 
-    hipLaunchKernelGGL(k_fill_i16, dim3(gip_div_up(w, 256), h, batch), dim3(256), 0, st, disp, disp_pitch / 2, w, h, g.filtered, disp_bstride);
-    GIP_LAUNCH_CHECK();
+    if (!skip_fill) {
+        hipLaunchKernelGGL(k_fill_i16, dim3(gip_div_up(w, 256), h, batch), dim3(256), 0, st, disp, disp_pitch / 2, w, h, g.filtered, disp_bstride);
+        GIP_LAUNCH_CHECK();
+    }
     if (g.degenerate) return GIP_OK;
 
     BmArgs a;
@@ -521,6 +531,12 @@ extern "C" int gipk_bm_match(const uint8_t* left, const uint8_t* right, size_t p
         a.TC = TC;
         int ntiles = gip_div_up(a.nleft, TC) + gip_div_up(a.nright, TC);
         int nch = pick_chunks(ntiles);
+        if (c4_done || fast_ok) {
+            // border-only launch: tiny blocks whose per-row global loads are latency bound -- use short row chunks so that
+            // many small workgroups overlap (the extra 2r warm-up rows are cheap next to the idle time they remove)
+            int short_rows = 2 * r + 8;
+            nch = gip_div_up(nrows, short_rows);
+        }
         a.rows_per_chunk = gip_div_up(nrows, nch);
         nch = gip_div_up(nrows, a.rows_per_chunk);
         size_t sh = smem_bytes(2 * r + 1, TC + 2 * r, TC + 2 * r + g.ndisp + 8, TC, g.ndisp, S);
