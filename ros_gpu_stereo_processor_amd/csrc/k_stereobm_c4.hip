@@ -24,6 +24,7 @@
 #include "gip_internal.h"
 #include "bm_common.h"
 
+#include <cmath>
 #include <type_traits>
 #include <utility>
 
@@ -208,8 +209,17 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     const int my_col = 4 * t + s;                 // the tile column this lane finalises
     const int c_out = c0 + my_col;
     const bool writer = (t >= K) && (t <= 15 - K) && (c_out >= a.cbeg) && (c_out < a.cend);
+#if 1
+    // cost slice rows ordered [q][t] (row = 16q + t): the stores of consecutive lanes are CSPB = 4 (mod 32) dwords apart
+    // (bank-conflict free); lane (s,t) finalises column 4t+s, whose row is 16s + t = its own lane index
+    constexpr int QSTRIDE = 16 * CSPB;
+    uint8_t* csrow_w = cs + (size_t)t * CSPB + (size_t)(4 * NG * s) * 2;
+    const uint8_t* csrow_r = cs + (size_t)lane * CSPB;
+#else
+    constexpr int QSTRIDE = CSPB;
     uint8_t* csrow_w = cs + (size_t)(4 * t) * CSPB + (size_t)(4 * NG * s) * 2;   // where this lane parks (column 4t+q, its groups)
     const uint8_t* csrow_r = cs + (size_t)my_col * CSPB;
+#endif
 
     for (int y = ya; y < yb; y++) {
         __syncthreads();          // single wave: orders the LDS traffic of the previous iteration before the slot is reused
@@ -240,7 +250,7 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
                 u32 gm = umin(m & 0xFFFFu, m >> 16);
                 gmin[q][g] = gm;
                 best[q] = umin(best[q], (gm << 8) | (u32)(NG * s + g));
-                *(uint2*)(csrow_w + (size_t)q * CSPB + g * 8) = make_uint2(H.lo, H.hi);
+                *(uint2*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint2(H.lo, H.hi);
             });
         }
         // texture sums (32-bit, same window)
@@ -335,11 +345,35 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st)
     const int ncols = a.cend - a.cbeg;
     const int ntiles = (ncols + (64 - 8 * K) - 1) / (64 - 8 * K);
     const int nrows = a.row1 - a.row0;
-    // row chunks: fill the chip (~2048 waves at 8 per CU) while keeping the 2R-row warm-up small
-    int want = (4096 + ntiles * batch - 1) / (ntiles * batch);
-    int maxchunks = nrows / (6 * R + 6);
-    if (maxchunks < 1) maxchunks = 1;
-    int nch = want < 1 ? 1 : (want > maxchunks ? maxchunks : want);
+    // Row chunks.  One workgroup = one wave; a CU holds floor(160 KiB / LDS per wave) of them (at most 32).  Pick the
+    // chunk count that minimises  rounds x (rows per chunk + warm-up cost): whole "rounds" of resident waves matter because
+    // a partially filled last round idles most of the chip, and every chunk re-reads 2R warm-up rows (each worth about
+    // 0.4 of a full row: SAD only, no winner-take-all).
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+        else n_cu = 256;
+    }
+    int per_cu = (int)((160 * 1024) / (sh ? sh : 1));
+    if (per_cu > 32) per_cu = 32;
+    if (per_cu < 1) per_cu = 1;
+#ifdef C4_FIXED_CHUNKS
+    int nch = C4_FIXED_CHUNKS;
+#else
+    const double capacity = (double)n_cu * per_cu;
+    int nch = 1;
+    double best_cost = 1e300;
+    const int max_nch = nrows / (2 * R + 2) > 0 ? nrows / (2 * R + 2) : 1;
+    for (int c = 1; c <= max_nch && c <= 64; c++) {
+        const int rpc = (nrows + c - 1) / c;
+        const int real_c = (nrows + rpc - 1) / rpc;
+        const double wgs = (double)ntiles * real_c * batch;
+        const double rounds = wgs / capacity < 1.0 ? 1.0 : ceil(wgs / capacity - 1e-9);
+        const double cost = rounds * (rpc + 0.4 * 2 * R);
+        if (cost < best_cost - 1e-9) { best_cost = cost; nch = real_c; }
+    }
+#endif
     BmArgs b = a;
     b.rows_per_chunk = (nrows + nch - 1) / nch;
     nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;

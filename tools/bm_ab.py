@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""A/B timing of gipk_stereobm (prefilter + matcher + finalize) from two library builds in ONE process, interleaved rounds,
+same inputs (rule: never compare timings taken on different devices).  usage: bm_ab.py libA.so libB.so [batch]"""
+import ctypes as C, sys, os, statistics
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ros_gpu_stereo_processor_amd import capi, synth
+
+W, H, B = 1242, 375, 64
+paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+libs = [C.CDLL(os.path.abspath(p)) for p in paths]
+for L in libs:
+    L.gipk_stereobm_scratch_bytes.restype = C.c_size_t
+    L.gipk_stereobm_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(capi.BMParams)]
+    L.gipk_stereobm.argtypes = capi.PROTOTYPES["gipk_stereobm"][1]
+dev = torch.device("cuda:0")
+pairs = [synth.rectified_pair(W, H, 128, seed=300 + i)[:2] for i in range(4)]
+l = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).to(dev)
+r = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).to(dev)
+p = capi.BMParams(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=9, min_disparity=0, num_disparities=128, texture_threshold=10,
+                  uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+outs, scr = [], []
+for L in libs:
+    n = L.gipk_stereobm_scratch_bytes(W, H, B, C.byref(p))
+    scr.append(torch.empty(n, dtype=torch.uint8, device=dev))
+    outs.append(torch.empty((B, H, W), dtype=torch.int16, device=dev))
+
+def run(i):
+    L = libs[i]
+    rc = L.gipk_stereobm(l.data_ptr(), r.data_ptr(), W, W, H, C.byref(p), outs[i].data_ptr(), W * 2, scr[i].data_ptr(), scr[i].numel(), B, H * W, H * W * 2, None)
+    assert rc == 0, rc
+
+N = len(libs)
+for i in range(N):
+    run(i)
+torch.cuda.synchronize()
+print("outputs identical:", all(bool(torch.equal(outs[0], outs[i])) for i in range(1, N)))
+times = [[] for _ in range(N)]
+for rnd in range(12):
+    for i in range(N):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            run(i)
+        e1.record()
+        torch.cuda.synchronize()
+        times[i].append(e0.elapsed_time(e1) / 5)
+for i in range(N):
+    print("%s: median %.3f ms  min %.3f ms  (per %d pairs)" % (os.path.basename(paths[i]), statistics.median(times[i]), min(times[i]), B))
