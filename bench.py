@@ -98,17 +98,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from ros_gpu_stereo_processor_amd import dist as gdist
     B = args.batch
-    lraw, rraw, calib = make_inputs(B, seed0=100 + 16 * rank)
+    lraw, rraw, calib0 = make_inputs(B, seed0=100 + 16 * rank)
+    # Calibration + rectification tables: rank 0 owns the CameraInfo, builds the fixed-point tables on its host (double
+    # precision) and broadcasts both once over RCCL (xGMI); the other ranks run on exactly those tables.  Frames are
+    # independent units (frame i -> rank i mod N, dist.frame_shard), so no collective follows on the data path.
+    calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
     params = capi.BMParams(**bm_kwargs())
     outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
     pipe = BatchPipeline(W, H, calib, params, B, "mono8", outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True)
-
-    # rectification tables: rank 0's host-built tables, broadcast once over RCCL (xGMI); no per-frame collective follows
-    maps = pipe.host_maps_to_device() if rank == 0 else pipe.empty_maps()
-    if world > 1:
-        for m in maps:
-            dist.broadcast(m, src=0)
     pipe.install_maps(maps)
 
     left = torch.from_numpy(lraw).to(dev)
@@ -133,16 +132,13 @@ def main():
     dt = time.perf_counter() - t0
     bm_ms_sum, total_ms_sum, runs = pipe.timing_read()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    dt_max = gdist.max_over_ranks(dt, dev)
 
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / dt_max
         bm_ms = bm_ms_sum / max(runs, 1)
-        # dominant kernel: k_bm_fast (SAD block matcher on the prefiltered rectified pair).  Algorithmic bytes per
+        # dominant kernel: k_bm_c4 (SAD block matcher on the prefiltered rectified pair).  Algorithmic bytes per
         # stereo pair = 4*W*H (prefiltered L + R read once, int16 disparity written once; SURVEY.md section 8d,
         # "SAD-only kernel on rectified input"); one launch processes B pairs.
         algo_bytes = 4.0 * W * H * B
@@ -163,7 +159,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI-size 1242x375 mono8, ndisp=128 block=9, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
                                    "->speckle(800,5)->f32 disparity+PointCloud2", "pairs_per_step_per_gpu": B, "parallelism": "frame-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_bm_fast<64,3>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_bm_c4<8,4>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_ms": round(bm_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4)},
         }

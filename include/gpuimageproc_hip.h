@@ -177,6 +177,8 @@ int gip_init_stereo_model_files(gip_handle h, const char *left_cal_file, const c
 int gip_is_stereo_model_initialised(gip_handle h); /* :63 */
 int gip_read_calibration(const char *file, gip_camera_info *out, char *camera_name, size_t name_len);
 /* model accessors used by senders/tests */
+/* host-only (no device needed): the fixed-point rectification tables of one camera, as initStereoModel builds them */
+int gip_build_rectify_maps(const gip_camera_info *info, int16_t *map1, uint16_t *map2);
 int gip_model_size(gip_handle h, int *width, int *height);
 int gip_model_get(gip_handle h, double *fx, double *fy, double *cx_l, double *cy, double *cx_r, double *baseline, double Q[16]);
 /* remap tables as built on the host (double), for broadcasting to other ranks: map1 = w*h*2 int16, map2 = w*h uint16 */

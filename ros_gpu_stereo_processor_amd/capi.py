@@ -100,6 +100,7 @@ PROTOTYPES = {
     "gip_init_stereo_model_files": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "gip_is_stereo_model_initialised": (_i, [_vp]),
     "gip_read_calibration": (_i, [C.c_char_p, C.POINTER(CameraInfo), C.c_char_p, _sz]),
+    "gip_build_rectify_maps": (_i, [C.POINTER(CameraInfo), _vp, _vp]),
     "gip_model_size": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "gip_model_get": (_i, [_vp] + [C.POINTER(_d)] * 6 + [C.POINTER(_d)]),
     "gip_get_rectify_maps": (_i, [_vp, _i, _vp, _vp]),

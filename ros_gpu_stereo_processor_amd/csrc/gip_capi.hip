@@ -429,6 +429,18 @@ int gip_init_stereo_model_files(gip_handle h, const char* left_cal_file, const c
 
 int gip_is_stereo_model_initialised(gip_handle h) { return h && h->model.initialised ? 1 : 0; }
 
+int gip_build_rectify_maps(const gip_camera_info* info, int16_t* map1, uint16_t* map2)
+{
+    if (!info || !map1 || !map2 || info->width <= 0 || info->height <= 0 || info->width > 32767 || info->height > 32767 || info->nD < 0 || info->nD > 8)
+        return GIP_ERR_INVALID_ARG;
+    std::vector<int16_t> m1;
+    std::vector<uint16_t> m2;
+    gip_build_rectify_map(*info, m1, m2);
+    std::memcpy(map1, m1.data(), m1.size() * sizeof(int16_t));
+    std::memcpy(map2, m2.data(), m2.size() * sizeof(uint16_t));
+    return GIP_OK;
+}
+
 int gip_model_size(gip_handle h, int* width, int* height)
 {
     H_CHECK(h);
