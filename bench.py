@@ -161,7 +161,13 @@ def main():
                                    "->speckle(800,5)->f32 disparity+PointCloud2", "pairs_per_step_per_gpu": B, "parallelism": "frame-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_bm_c4<8,4>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_ms": round(bm_ms, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4)},
+                         "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4),
+                         # the search is integer-VALU bound, not HBM bound: (pixel, disparity) pairs per second
+                         # against the measured 4.2-cycle VOP3 issue rate (tools/ubench_valu.hip: 39.3 T lane-slots/s) at the
+                         # kernel's ~7.4 issue slots per pair (instruction count of k_bm_c4<8,4>)
+                         "valu_model": {"px_disp_pairs_per_s": round(W * H * NDISP * B / (bm_ms * 1e-3), 1) if bm_ms > 0 else 0.0,
+                                        "slots_per_pair": 7.4, "peak_lane_slots_per_s": 39.3e12,
+                                        "frac": round(W * H * NDISP * B / (bm_ms * 1e-3) * 7.4 / 39.3e12, 4) if bm_ms > 0 else 0.0}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lraw[:4], rraw[:4], calib)
