@@ -73,6 +73,30 @@ def cpu_baseline(lraw, rraw, calib, budget_s=12.0, max_pairs=64):
                        "in %.1f s with the C oracle (OpenMP over row stripes); OpenCV itself is not installable here" % (n, dt))
 
 
+def single_pair_latency(lraw, rraw, calib, params, device, iters=30):
+    """ms per frame when ONE pair goes through the reference's per-frame schedule (gip_process_pair = StereoProcessor::imageCb,
+    Disparity + Pointcloud connected): pinned upload of both raws, the whole chain, stream sync.  Not part of `value`."""
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd import processor as P
+    proc = P.GpuStereoProcessor(device)
+    proc.initStereoModel(P.camera_info(W, H, **calib["left"]), P.camera_info(W, H, **calib["right"]))
+    proc.setParams(params)
+    proc.setMaxSpeckleSize(SPECKLE_SIZE)
+    proc.setMaxSpeckleDiff(SPECKLE_DIFF)
+    mask = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
+    for _ in range(3):
+        proc.processPair(lraw, rraw, "mono8", mask)
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        proc.processPair(lraw, rraw, "mono8", mask)
+        ts.append(1e3 * (time.perf_counter() - t0))
+    proc.close()
+    ts.sort()
+    return {"single_pair_ms_p50": round(ts[len(ts) // 2], 4), "single_pair_ms_p99": round(ts[min(len(ts) - 1, int(0.99 * len(ts)))], 4),
+            "what": "gip_process_pair (imageCb schedule: upload L/R, mono, rectify L/R + colour L, StereoBM, speckle, reproject) for one 1242x375 pair, host wall time incl. sync"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +193,8 @@ def main():
                                         "slots_per_pair": 7.4, "peak_lane_slots_per_s": 39.3e12,
                                         "frac": round(W * H * NDISP * B / (bm_ms * 1e-3) * 7.4 / 39.3e12, 4) if bm_ms > 0 else 0.0}},
         }
+        if world == 1:
+            out["latency"] = single_pair_latency(lraw[0], rraw[0], calib, params, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lraw[:4], rraw[:4], calib)
         print(json.dumps(out), flush=True)

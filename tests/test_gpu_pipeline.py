@@ -58,3 +58,58 @@ def test_batch_pipeline_matches_oracle(gpu, oracle, encoding):
         assert np.array_equal(pc[b][..., 12:], epc[..., 12:])
         assert (exp != -16).mean() > 0.2
     pipe.close()
+
+
+def test_config3_1080p_bayer_nd256_block21_speckle(gpu, oracle):
+    """BASELINE.json configs[2]: 1920x1080 bayer_rggb8 pair, ndisp 256, block 21 + speckle filter, full chain on one GPU.
+    One frame is checked bit-exactly against the oracle (a few seconds of CPU)."""
+    import torch
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+    O = oracle
+    w, h, nd, B = 1920, 1080, 256, 2
+    calib = synth.scaled_calibration(w, h)
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=21, min_disparity=0, num_disparities=nd, texture_threshold=10,
+              uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    raws = [synth.raw_pair(w, h, nd, seed=80 + i, calib=calib)[:2] for i in range(B)]
+    L = np.stack([synth.bayer_mosaic(synth.colorize(r[0], 1), "bayer_rggb8") for r in raws])
+    R = np.stack([synth.bayer_mosaic(synth.colorize(r[1], 2), "bayer_rggb8") for r in raws])
+    pipe = BatchPipeline(w, h, calib, capi.BMParams(**kw), B, "bayer_rggb8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 0, 800, 5.0)
+    pipe.install_maps(pipe.host_maps_to_device())
+    pipe.run(torch.from_numpy(L).to(gpu), torch.from_numpy(R).to(gpu))
+    torch.cuda.synchronize()
+    d16 = pipe.disparity.cpu().numpy()
+    ml = O.init_undistort_rectify_map(calib["left"]["K"], calib["left"]["D"], calib["left"]["R"], calib["left"]["P"], w, h)
+    mr = O.init_undistort_rectify_map(calib["right"]["K"], calib["right"]["D"], calib["right"]["R"], calib["right"]["P"], w, h)
+    b = 1
+    rl = O.remap(O.bayer_to_gray(L[b], "bayer_rggb8"), *ml)
+    rr = O.remap(O.bayer_to_gray(R[b], "bayer_rggb8"), *mr)
+    exp = O.filter_speckles(O.stereobm(rl, rr, O.bm_params(**kw)), -16, 800, 80)
+    assert np.array_equal(d16[b], exp)
+    assert (exp != -16).mean() > 0.2
+    pc = pipe.pointcloud.cpu().numpy()[b]
+    assert np.array_equal(pc[..., 16:19], O.remap(O.bayer_to_bgr(L[b], "bayer_rggb8"), *ml))
+    assert np.array_equal(np.isnan(pc[..., :4].copy().view(np.float32)[..., 0]) | (exp == 0), (exp == -16) | (exp == 0))
+    pipe.close()
+
+
+def test_config5_4k_nd192_block15_properties(gpu, oracle):
+    """BASELINE.json configs[4] size (4096x2160 mono8, ndisp 192, block 15) on ONE GPU (the 4-GPU row-tile split is not
+    built yet): a horizontal band is checked bit-exactly against the oracle run on the same band (StereoBM rows are
+    independent beyond the block radius), plus range / ROI invariants on the full frame."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    import torch
+    w, h, nd, block = 4096, 2160, 192, 15
+    l, r, _ = synth.rectified_pair(w, h, nd, seed=91, nrect=8)
+    kw = dict(block_size=block, num_disparities=nd, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1)
+    got = K.stereobm(torch.from_numpy(l).to(gpu), torch.from_numpy(r).to(gpu), K.bm_params(**kw)).cpu().numpy()
+    valid = got != -16
+    assert got[valid].min() >= 0 and got[valid].max() <= (nd - 1) * 16 and valid.mean() > 0.3
+    roi = oracle.valid_disparity_roi(w, h, oracle.bm_params(**kw))
+    mask = np.ones((h, w), bool)
+    mask[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]] = False
+    assert (got[mask] == -16).all()
+    # band of 200 output rows: the oracle needs the band plus (block radius + 1 prefilter row) of context on each side
+    y0, y1, ctx = 900, 1100, block // 2 + 2
+    band = oracle.stereobm(l[y0 - ctx:y1 + ctx], r[y0 - ctx:y1 + ctx], oracle.bm_params(**kw))
+    assert np.array_equal(got[y0:y1], band[ctx:ctx + (y1 - y0)])
