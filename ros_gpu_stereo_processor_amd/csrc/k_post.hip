@@ -92,8 +92,9 @@ __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, f
 //
 // Run-based CCL (the union-find nodes are horizontal RUNS, not pixels, so the number of global atomics scales with the
 // number of run overlaps instead of the number of pixels):
-//   k_spk_runs   one workgroup per image row: every valid pixel gets the index of the first pixel of its run
-//                (segmented max-scan in LDS); run starts point to themselves; the last pixel of a run stores its length
+//   k_spk_runs   one workgroup per image row: every valid pixel gets the COLUMN of the first pixel of its run (u16, the only
+//                dense scratch array; segmented max-scan in LDS); run starts initialise their union-find node (parent =
+//                self, size 0); the last pixel of a run stores the run length at the start
 //   k_spk_merge  one union per maximal overlap segment between runs of adjacent rows (atomicMin union-find on run starts)
 //   k_spk_sizes  every run start: root = find(); atomicAdd(size[root], run length); path compression
 //   k_spk_apply  pixels whose component has <= maxSpeckleSize pixels become newVal
@@ -137,9 +138,11 @@ __device__ __forceinline__ bool spk_conn(int a, int b, int new_val, int max_diff
 
 constexpr int SPK_TPB = 256;
 
-// lab[i]: valid pixel -> index (within the frame) of its run's first pixel; invalid -> -1.   rlen[start] = run length.
-__global__ void __launch_bounds__(SPK_TPB) k_spk_runs(const int16_t* __restrict__ disp, size_t dpitch, int* __restrict__ lab, int* __restrict__ rlen,
-                                                       int* __restrict__ sizes, int w, int h, int new_val, int max_diff, size_t dbs)
+// Scratch per pixel: start16 (u16: column of the pixel's run start, 0xFFFF = invalid pixel) is the only DENSE array;
+// parent / rlen / csize (int32) are touched only at run-start pixels.
+__global__ void __launch_bounds__(SPK_TPB) k_spk_runs(const int16_t* __restrict__ disp, size_t dpitch, unsigned short* __restrict__ start16,
+                                                       int* __restrict__ parent, int* __restrict__ rlen, int* __restrict__ csize, int w, int h, int new_val,
+                                                       int max_diff, size_t dbs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     short* row = (short*)smem_raw;                 // w values (+1 pad)
@@ -169,23 +172,24 @@ __global__ void __launch_bounds__(SPK_TPB) k_spk_runs(const int16_t* __restrict_
         __syncthreads();
     }
     int running = t > 0 ? part[t - 1] : -1;
-    // pass 2: labels, run lengths
+    // pass 2: run start of every pixel; run starts initialise their union-find node, the run's last pixel stores its length
     for (int x = x0; x < x1; x++) {
         int v = row[x];
         bool valid = v != new_val;
         bool start = valid && (x == 0 || !spk_conn(row[x - 1], v, new_val, max_diff));
-        if (start) running = x;
-        lab[base + x] = valid ? y * w + running : -1;
-        sizes[base + x] = 0;
-        // rlen > 0 marks exactly the run starts: non-starts are zeroed here, a start is written by whichever thread
-        // owns the run's LAST pixel (disjoint addresses, every run has one last pixel)
-        if (!start) rlen[base + x] = 0;
+        if (start) {
+            running = x;
+            parent[base + x] = y * w + x;
+            csize[base + x] = 0;
+        }
+        start16[base + x] = valid ? (unsigned short)running : (unsigned short)0xFFFFu;
         bool last_of_run = valid && (x == w - 1 || !spk_conn(v, row[x + 1], new_val, max_diff));
         if (last_of_run) rlen[base + running] = x - running + 1;
     }
 }
 
-__global__ void k_spk_merge(const int16_t* __restrict__ disp, size_t dpitch, int* __restrict__ lab, int w, int h, int new_val, int max_diff, size_t dbs)
+__global__ void k_spk_merge(const int16_t* __restrict__ disp, size_t dpitch, const unsigned short* __restrict__ start16, int* __restrict__ parent,
+                            int w, int h, int new_val, int max_diff, size_t dbs)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w || y + 1 >= h) return;
@@ -198,41 +202,36 @@ __global__ void k_spk_merge(const int16_t* __restrict__ disp, size_t dpitch, int
         int al = d0[x - 1], bl = d1[x - 1];
         if (spk_conn(al, a, new_val, max_diff) && spk_conn(bl, b, new_val, max_diff) && spk_conn(al, bl, new_val, max_diff)) return;
     }
-    int* L = lab + blockIdx.z * (size_t)w * h;
+    const size_t base = blockIdx.z * (size_t)w * h;
     const int i = y * w + x;
-    // entries of non-start pixels are never modified (atomics only hit run starts), so they still name the run start
-    uf_union(L, L[i], L[i + w]);
+    uf_union(parent + base, y * w + (int)start16[base + i], (y + 1) * w + (int)start16[base + i + w]);
 }
 
-__global__ void k_spk_sizes(int* __restrict__ lab, const int* __restrict__ rlen, int* __restrict__ sizes, int w, int h)
+__global__ void k_spk_sizes(const unsigned short* __restrict__ start16, int* __restrict__ parent, const int* __restrict__ rlen, int* __restrict__ csize,
+                            int w, int h)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const size_t base = blockIdx.z * (size_t)w * h;
     const int i = y * w + x;
-    int p = lab[base + i];
-    if (p < 0) return;
-    const int len = rlen[base + i];
-    if (len <= 0) return;  // not a run start
-    int root = p;
-    int q = lab[base + root];
-    while (q != root) { root = q; q = lab[base + root]; }   // the merge kernel is complete: plain loads are coherent
-    lab[base + i] = root;                                    // compression: starts now point straight at their root
-    atomicAdd(&sizes[base + root], len);
+    if ((int)start16[base + i] != x) return;   // not a run start (0xFFFF never equals a column: w <= 32768)
+    int root = parent[base + i];
+    int q = parent[base + root];
+    while (q != root) { root = q; q = parent[base + root]; }   // the merge kernel is complete: plain loads are coherent
+    parent[base + i] = root;                                    // compression: starts now point straight at their root
+    atomicAdd(&csize[base + root], rlen[base + i]);
 }
 
-__global__ void k_spk_apply(int16_t* __restrict__ disp, size_t dpitch, const int* __restrict__ lab, const int* __restrict__ rlen,
-                            const int* __restrict__ sizes, int w, int h, int new_val, int max_size, size_t dbs)
+__global__ void k_spk_apply(int16_t* __restrict__ disp, size_t dpitch, const unsigned short* __restrict__ start16, const int* __restrict__ parent,
+                            const int* __restrict__ csize, int w, int h, int new_val, int max_size, size_t dbs)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const size_t base = blockIdx.z * (size_t)w * h;
-    const int i = y * w + x;
-    int p = lab[base + i];
-    if (p < 0) return;
-    // a start's entry holds the root (k_spk_sizes compressed it); any other pixel's entry names its run start
-    int root = rlen[base + i] > 0 ? p : lab[base + p];
-    if (sizes[base + root] <= max_size) ((int16_t*)((uint8_t*)disp + blockIdx.z * dbs))[(size_t)y * dpitch + x] = (int16_t)new_val;
+    const unsigned s = start16[base + y * w + x];
+    if (s == 0xFFFFu) return;
+    const int root = parent[base + y * w + (int)s];   // a start's entry holds its root (k_spk_sizes compressed it)
+    if (csize[base + root] <= max_size) ((int16_t*)((uint8_t*)disp + blockIdx.z * dbs))[(size_t)y * dpitch + x] = (int16_t)new_val;
 }
 
 // ---------------------------------------------------------------------------------------- reprojection / cloud
@@ -370,7 +369,7 @@ int gipk_disparity_to_f32(const int16_t* disp, size_t disp_pitch, float* dst, si
     return GIP_OK;
 }
 
-size_t gipk_speckle_scratch_bytes(int w, int h, int batch) { return (size_t)w * h * batch * 12; }
+size_t gipk_speckle_scratch_bytes(int w, int h, int batch) { return (size_t)w * h * batch * 14 + 64; }
 
 int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff, void* scratch,
                          size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream)
@@ -379,17 +378,18 @@ int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new
     GIPK_ARGCHECK(scratch_bytes >= gipk_speckle_scratch_bytes(w, h, batch) && (size_t)w * h < (1u << 31));
     if (w > 32768) return GIP_ERR_UNSUPPORTED;
     const size_t n = (size_t)w * h * batch;
-    int* lab = (int*)scratch;
-    int* rlen = lab + n;
-    int* sizes = rlen + n;
+    int* parent = (int*)gip_align_up((size_t)(uintptr_t)scratch, 16);
+    int* rlen = parent + n;
+    int* csize = rlen + n;
+    unsigned short* start16 = (unsigned short*)(csize + n);
     hipStream_t st = (hipStream_t)stream;
     dim3 g = grid2d(w, h, batch);
     size_t sh = (((size_t)w * 2 + 2 + 15) & ~(size_t)15) + SPK_TPB * sizeof(int);
     if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_spk_runs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(k_spk_runs, dim3(h, 1, batch), dim3(SPK_TPB), sh, st, disp, disp_pitch / 2, lab, rlen, sizes, w, h, new_val, max_diff, disp_bstride);
-    hipLaunchKernelGGL(k_spk_merge, g, dim3(TPB), 0, st, disp, disp_pitch / 2, lab, w, h, new_val, max_diff, disp_bstride);
-    hipLaunchKernelGGL(k_spk_sizes, g, dim3(TPB), 0, st, lab, rlen, sizes, w, h);
-    hipLaunchKernelGGL(k_spk_apply, g, dim3(TPB), 0, st, disp, disp_pitch / 2, lab, rlen, sizes, w, h, new_val, max_speckle_size, disp_bstride);
+    hipLaunchKernelGGL(k_spk_runs, dim3(h, 1, batch), dim3(SPK_TPB), sh, st, disp, disp_pitch / 2, start16, parent, rlen, csize, w, h, new_val, max_diff, disp_bstride);
+    hipLaunchKernelGGL(k_spk_merge, g, dim3(TPB), 0, st, disp, disp_pitch / 2, start16, parent, w, h, new_val, max_diff, disp_bstride);
+    hipLaunchKernelGGL(k_spk_sizes, g, dim3(TPB), 0, st, start16, parent, rlen, csize, w, h);
+    hipLaunchKernelGGL(k_spk_apply, g, dim3(TPB), 0, st, disp, disp_pitch / 2, start16, parent, csize, w, h, new_val, max_speckle_size, disp_bstride);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
