@@ -147,13 +147,15 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     };
 
     // ---- state
-    u32 Vlo[4][NG], Vhi[4][NG];   // vertical column sums, 4 x u16 per (column q, group g)
+    // vertical column sums, 4 x u16 per (column q, group g), kept as 64-bit values so that v_mqsad accumulates in place in
+    // an aligned register pair (separate lo/hi arrays cost ~200 v_mov per row to assemble the pairs)
+    u64 V[4][NG];
     u32 TV[4];                    // vertical column sums of |L - ftzero|
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         TV[q] = 0;
 #pragma unroll
-        for (int g = 0; g < NG; g++) { Vlo[q][g] = 0; Vhi[q][g] = 0; }
+        for (int g = 0; g < NG; g++) V[q][g] = 0;
     }
     const u32 ft1 = (u32)(a.ftzero + 1);
 
@@ -169,12 +171,7 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
             const u32 ref = lw & (0xFFu << (8 * q));
             TV[q] = __builtin_amdgcn_sad_u8(ref, ft1 << (8 * q), TV[q]);
 #pragma unroll
-            for (int g = 0; g < NG; g++) {
-                u64 acc = ((u64)Vhi[q][g] << 32) | Vlo[q][g];
-                acc = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, acc);
-                Vlo[q][g] = (u32)acc;
-                Vhi[q][g] = (u32)(acc >> 32);
-            }
+            for (int g = 0; g < NG; g++) V[q][g] = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, V[q][g]);
         }
     };
     auto sub_row = [&](int yy) {
@@ -190,9 +187,13 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
             TV[q] -= __builtin_amdgcn_sad_u8(ref, ft1 << (8 * q), 0u);
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                u64 tq = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, 0ull);
-                Vlo[q][g] -= (u32)tq;           // lane-wise V >= t: no borrow crosses the packed halves
-                Vhi[q][g] -= (u32)(tq >> 32);
+                const u64 tq = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, 0ull);
+                // lane-wise V >= t, so two independent 32-bit subtracts are exact; a 64-bit subtract would chain every pair
+                // through VCC (v_sub_co / v_subb) and serialise the whole row
+                u32 lo, hi;
+                asm("v_sub_u32 %0, %1, %2" : "=v"(lo) : "v"((u32)V[q][g]), "v"((u32)tq));
+                asm("v_sub_u32 %0, %1, %2" : "=v"(hi) : "v"((u32)(V[q][g] >> 32)), "v"((u32)(tq >> 32)));
+                V[q][g] = ((u64)hi << 32) | lo;
             }
         }
     };
@@ -235,10 +236,10 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
         for (int g = 0; g < NG; g++) {
             P2 P[5];
             P[0] = {0u, 0u};
-            P[1] = {Vlo[0][g], Vhi[0][g]};
-            P[2] = P[1] + P2{Vlo[1][g], Vhi[1][g]};
-            P[3] = P[2] + P2{Vlo[2][g], Vhi[2][g]};
-            P[4] = P[3] + P2{Vlo[3][g], Vhi[3][g]};
+            P[1] = {(u32)V[0][g], (u32)(V[0][g] >> 32)};
+            P[2] = P[1] + P2{(u32)V[1][g], (u32)(V[1][g] >> 32)};
+            P[3] = P[2] + P2{(u32)V[2][g], (u32)(V[2][g] >> 32)};
+            P[4] = P[3] + P2{(u32)V[3][g], (u32)(V[3][g] >> 32)};
             auto shift = [](auto dv, P2 v) -> P2 {
                 constexpr int d = decltype(dv)::value;
                 return P2{lane_at<d>(v.lo), lane_at<d>(v.hi)};
