@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="stereo pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     args = ap.parse_args()
 
     import torch
@@ -193,7 +194,7 @@ def main():
                                         "slots_per_pair": 7.4, "peak_lane_slots_per_s": 39.3e12,
                                         "frac": round(W * H * NDISP * B / (bm_ms * 1e-3) * 7.4 / 39.3e12, 4) if bm_ms > 0 else 0.0}},
         }
-        if world == 1:
+        if world == 1 and not args.no_latency:
             out["latency"] = single_pair_latency(lraw[0], rraw[0], calib, params, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lraw[:4], rraw[:4], calib)

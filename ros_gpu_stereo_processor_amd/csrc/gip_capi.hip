@@ -1105,13 +1105,15 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     }
     (void)raw_cn;
     // stage 2: rectify (StereoProcessor.cpp:220-256)
+    // rectified mono planes: rows padded to 64 bytes so the prefilter can work on aligned dwords
+    const size_t rp = gip_align_up((size_t)w, 64), rplane = rp * hh;
     for (int i = 0; i < 2; i++) {
-        B_STEP(ensure_dev(h, h->b_rect[i], npx * B), "batch buffers");
+        B_STEP(ensure_dev(h, h->b_rect[i], rplane * B), "batch buffers");
         const GipPinhole& cam = i == 0 ? h->model.left : h->model.right;
         if (cam.distorted)
-            B_STEP(gipk_remap_u8(mono[i], w, w, hh, (uint8_t*)h->b_rect[i].p, w, w, hh, 1, h->d_map1[i], h->d_map2[i], B, npx, npx, st), "rectify");
+            B_STEP(gipk_remap_u8(mono[i], w, w, hh, (uint8_t*)h->b_rect[i].p, rp, w, hh, 1, h->d_map1[i], h->d_map2[i], B, npx, rplane, st), "rectify");
         else
-            H_HIP(h, hipMemcpyAsync(h->b_rect[i].p, mono[i], npx * B, hipMemcpyDeviceToDevice, st));
+            H_HIP(h, hipMemcpy2DAsync(h->b_rect[i].p, rp, mono[i], w, w, (size_t)hh * B, hipMemcpyDeviceToDevice, st));
     }
     const uint8_t* rect_color = nullptr;
     int rect_color_cn = 3;
@@ -1134,7 +1136,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     B_STEP(ensure_dev(h, h->bm_scratch, gipk_stereobm_scratch_bytes(w, hh, B, &bp)), "batch buffers");
     g_bm_ev0 = ev[0];
     g_bm_ev1 = ev[1];
-    rc = gipk_stereobm((const uint8_t*)h->b_rect[0].p, (const uint8_t*)h->b_rect[1].p, w, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, npx,
+    rc = gipk_stereobm((const uint8_t*)h->b_rect[0].p, (const uint8_t*)h->b_rect[1].p, rp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, rplane,
                        npx * 2, st);
     g_bm_ev0 = g_bm_ev1 = nullptr;
     if (rc != GIP_OK) return propagate(h, rc, "stereobm");
@@ -1145,8 +1147,9 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     }
     // stage 5: float disparity (GPUStereoProcessor.cpp:320) + cloud (StereoProcessor.cpp:278-282, GpuSenderPc2.cpp) in one pass
     if (d->disparity_f32 || want_pc)
-        B_STEP(gipk_disparity_outputs(d->disparity, (size_t)w * 2, rect_color, (size_t)w * rect_color_cn, rect_color_cn, d->disparity_f32, want_pc ? d->pointcloud : nullptr, w, hh,
-                                      h->model.Q, h->model.left.cx(), h->model.right.cx(), bp.min_disparity, B, npx * 2, npx * rect_color_cn, st), "disparity outputs");
+        B_STEP(gipk_disparity_outputs(d->disparity, (size_t)w * 2, rect_color, rect_color_cn == 1 ? rp : (size_t)w * 3, rect_color_cn, d->disparity_f32,
+                                      want_pc ? d->pointcloud : nullptr, w, hh, h->model.Q, h->model.left.cx(), h->model.right.cx(), bp.min_disparity, B, npx * 2,
+                                      rect_color_cn == 1 ? rplane : npx * 3, st), "disparity outputs");
     H_HIP(h, hipEventRecord(ev[3], st));
     h->timing_runs++;
 #undef B_STEP

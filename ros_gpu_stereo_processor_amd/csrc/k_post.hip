@@ -262,8 +262,11 @@ __device__ __forceinline__ void store_pc2_record(uint8_t* rec, float X, float Y,
     const float nanv = __builtin_nanf("");
     float4 a = make_float4(valid ? X : nanv, valid ? Y : nanv, valid ? Z : nanv, 0.f);
     uint4 b = make_uint4(bgr, 0u, 0u, 0u);
-    ((float4*)rec)[0] = a;       // x y z + 4 pad bytes (0)
-    ((uint4*)rec)[1] = b;        // rgb (b,g,r,0) + 12 pad bytes (0)
+    // write-once stream (0.95 GB per 64 frames): non-temporal stores keep it from displacing the tables / images in L2
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((f4){a.x, a.y, a.z, a.w}, (f4*)rec);          // x y z + 4 pad bytes (0)
+    __builtin_nontemporal_store((u4){b.x, b.y, b.z, b.w}, (u4*)rec + 1);      // rgb (b,g,r,0) + 12 pad bytes (0)
 }
 
 __global__ void k_pack_pc2(const float* __restrict__ xyz, size_t xpitch, const uint8_t* __restrict__ bgr, size_t bpitch, uint8_t* __restrict__ out,
