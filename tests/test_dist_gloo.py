@@ -60,3 +60,40 @@ def test_broadcast_and_sharding_world2(oracle):
     m1, m2 = D.build_maps_host(calib["left"], 320, 200)
     e1, e2 = oracle.init_undistort_rectify_map(calib["left"]["K"], calib["left"]["D"], calib["left"]["R"], calib["left"]["P"], 320, 200)
     assert np.array_equal(m1, e1) and np.array_equal(m2, e2)
+
+
+def _rowsplit_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ros_gpu_stereo_processor_amd import rowsplit as RS
+    h, w, halo = 37, 16, 5
+    full = torch.arange(h * w, dtype=torch.int32).reshape(h, w).to(torch.uint8)       # every rank can rebuild the truth
+    ranges = RS.plan(h, world)
+    y0, y1 = ranges[rank]
+    ext = RS.exchange_halos(full[y0:y1].clone(), rank, world, ranges, h, halo)
+    e0, e1 = RS.extended_range(h, y0, y1, halo)
+    ok = bool(torch.equal(ext, full[e0:e1])) and e0 % 2 == 0
+    # "compute" = identity on the extended tile, crop, gather on rank 0
+    mine = RS.crop_valid(ext.to(torch.int16), h, y0, y1, halo)
+    stitched = RS.gather_rows(mine, rank, world, ranges)
+    if rank == 0:
+        ok = ok and bool(torch.equal(stitched, full.to(torch.int16)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rowsplit_halo_exchange_world3():
+    """config 5 plumbing on CPU: halo exchange between neighbouring row tiles and gather of the result tiles (gloo, 3 ranks)."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rowsplit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -113,3 +113,19 @@ def test_config5_4k_nd192_block15_properties(gpu, oracle):
     y0, y1, ctx = 900, 1100, block // 2 + 2
     band = oracle.stereobm(l[y0 - ctx:y1 + ctx], r[y0 - ctx:y1 + ctx], oracle.bm_params(**kw))
     assert np.array_equal(got[y0:y1], band[ctx:ctx + (y1 - y0)])
+
+
+@pytest.mark.parametrize("shape,nd,block,world", [((540, 1024), 64, 9, 4), ((2160, 4096), 192, 15, 4), ((301, 640), 32, 21, 3)])
+def test_rowsplit_equals_full_frame(gpu, shape, nd, block, world):
+    """BASELINE.json configs[4] decomposition: the frame split into row tiles with halos (what each rank holds after the halo
+    exchange), matched tile by tile and stitched, equals the full-frame result bit for bit."""
+    import torch
+    from ros_gpu_stereo_processor_amd import kernels as K, rowsplit as RS
+    h, w = shape
+    l, r, _ = synth.rectified_pair(w, h, nd, seed=95, nrect=6)
+    lt, rt = torch.from_numpy(l).to(gpu), torch.from_numpy(r).to(gpu)
+    p = K.bm_params(block_size=block, num_disparities=nd, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1)
+    full = K.stereobm(lt, rt, p)
+    split = RS.split_stereobm_simulated(lt, rt, p, world, block)
+    assert torch.equal(full, split)
+    assert (full != -16).float().mean() > 0.2
