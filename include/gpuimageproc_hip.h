@@ -272,6 +272,11 @@ int gipk_remap_u8(const uint8_t *src, size_t src_pitch, int sw, int sh, uint8_t 
                   const int16_t *map1, const uint16_t *map2, int batch, size_t src_bstride, size_t dst_bstride,
                   gip_stream stream);
 
+/* same with cv::InterpolationFlags: GIP_INTER_LINEAR or GIP_INTER_NEAREST (fractions rounded half-up, as cv::remap does) */
+int gipk_remap_u8_interp(const uint8_t *src, size_t src_pitch, int sw, int sh, uint8_t *dst, size_t dst_pitch, int w, int h, int cn,
+                         const int16_t *map1, const uint16_t *map2, int interpolation, int batch, size_t src_bstride,
+                         size_t dst_bstride, gip_stream stream);
+
 int gipk_prefilter(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t dst_pitch, int w, int h, int prefilter_type,
                    int prefilter_size, int prefilter_cap, int batch, size_t src_bstride, size_t dst_bstride,
                    gip_stream stream);

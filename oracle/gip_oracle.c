@@ -294,6 +294,20 @@ void gipo_remap_bilinear_u8(const uint8_t *src, int src_step, int sw, int sh, ui
     }
 }
 
+/* cv::remap INTER_NEAREST with the same fixed-point maps: the 5-bit fractions are rounded half-up (NNDeltaTab_i of imgwarp.cpp) */
+void gipo_remap_nearest_u8(const uint8_t *src, int src_step, int sw, int sh, uint8_t *dst, int dst_step, int w, int h, int cn,
+                           const int16_t *map1, const uint16_t *map2)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t o = (size_t)y * w + x;
+            int a = map2[o] & 1023;
+            int sx = map1[2 * o] + ((a & 31) >= 16), sy = map1[2 * o + 1] + ((a >> 5) >= 16);
+            int in = (unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh;
+            for (int k = 0; k < cn; k++) dst[(size_t)y * dst_step + x * cn + k] = in ? src[(size_t)sy * src_step + sx * cn + k] : 0;
+        }
+}
+
 /* ======================================================================================
  * StereoBM.  Reference: GpuStereoProcessor::computeDisparity(cv::Mat&, cv::Mat&, cv::Mat&)
  * (src/GPUStereoProcessor.cpp:312-321) -> cv::StereoBM::compute (OpenCV 3.x calib3d/stereobm.cpp)

@@ -48,6 +48,9 @@ void gipo_init_undistort_rectify_map(const double K[9], const double *D, int nD,
 void gipo_remap_bilinear_u8(const uint8_t *src, int src_step, int sw, int sh, uint8_t *dst, int dst_step, int w, int h,
                             int cn, const int16_t *map1, const uint16_t *map2);
 
+void gipo_remap_nearest_u8(const uint8_t *src, int src_step, int sw, int sh, uint8_t *dst, int dst_step, int w, int h, int cn,
+                           const int16_t *map1, const uint16_t *map2);
+
 /* ---- StereoBM (reference: GPUStereoProcessor.cpp:312-321 -> cv::StereoBM::compute) ---- */
 enum { GIPO_PREFILTER_NORMALIZED_RESPONSE = 0, GIPO_PREFILTER_XSOBEL = 1 };
 

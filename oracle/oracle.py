@@ -155,13 +155,14 @@ def init_undistort_rectify_map(K, D, R, P, w, h):
     return map1, map2
 
 
-def remap(src, map1, map2):
+def remap(src, map1, map2, nearest=False):
     src = _u8(src)
     cn = 1 if src.ndim == 2 else src.shape[2]
     sh, sw = src.shape[:2]
     h, w = map2.shape
     out = np.empty((h, w) if cn == 1 else (h, w, cn), np.uint8)
-    lib().gipo_remap_bilinear_u8(_p(src), C.c_int(sw * cn), C.c_int(sw), C.c_int(sh), _p(out), C.c_int(w * cn), C.c_int(w),
+    fn = lib().gipo_remap_nearest_u8 if nearest else lib().gipo_remap_bilinear_u8
+    fn(_p(src), C.c_int(sw * cn), C.c_int(sw), C.c_int(sh), _p(out), C.c_int(w * cn), C.c_int(w),
                                  C.c_int(h), C.c_int(cn), _p(np.ascontiguousarray(map1)), _p(np.ascontiguousarray(map2)))
     return out
 

@@ -151,6 +151,7 @@ PROTOTYPES = {
     "gipk_cvt_mono8_to_mono16": (_i, [_vp, _sz, _vp, _sz, _i, _i, _i, _sz, _sz, _vp]),
     "gipk_cvt_mono16_to_mono8": (_i, [_vp, _sz, _vp, _sz, _i, _i, _i, _sz, _sz, _vp]),
     "gipk_remap_u8": (_i, [_vp, _sz, _i, _i, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _sz, _sz, _vp]),
+    "gipk_remap_u8_interp": (_i, [_vp, _sz, _i, _i, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _i, _sz, _sz, _vp]),
     "gipk_prefilter": (_i, [_vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i, _sz, _sz, _vp]),
     "gipk_bm_match": (_i, [_vp, _vp, _sz, _i, _i, C.POINTER(BMParams), _vp, _sz, _vp, _sz, _i, _sz, _sz, _sz, _vp]),
     "gipk_bm_finalize": (_i, [_vp, _sz, _vp, _sz, _i, _i, C.POINTER(BMParams), _i, _sz, _sz, _vp]),

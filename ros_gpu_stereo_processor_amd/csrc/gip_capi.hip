@@ -634,7 +634,8 @@ int gip_rectify_image(gip_handle h, int src_slot, int dst_slot, int interpolatio
     if (!h->model.initialised) return fail(h, GIP_ERR_NOT_INITIALISED, "rectifyImage: stereo model not initialised");
     Slot* src = slot_get(h, src_slot);
     if (!src) return fail(h, GIP_ERR_EMPTY_SLOT, "rectifyImage: source slot is empty");
-    if (interpolation != GIP_INTER_LINEAR) return fail(h, GIP_ERR_UNSUPPORTED, "rectifyImage: only INTER_LINEAR is implemented");
+    if (interpolation != GIP_INTER_LINEAR && interpolation != GIP_INTER_NEAREST)
+        return fail(h, GIP_ERR_UNSUPPORTED, "rectifyImage: only INTER_LINEAR and INTER_NEAREST are implemented");
     if (src->type != GIP_8UC1 && src->type != GIP_8UC3) return fail(h, GIP_ERR_UNSUPPORTED, "rectifyImage: 8UC1 / 8UC3 only");
     if (src->cols != h->map_w || src->rows != h->map_h) return fail(h, GIP_ERR_INVALID_ARG, "rectifyImage: image size differs from the calibration");
     H_HIP(h, hipSetDevice(h->device));
@@ -654,7 +655,8 @@ int gip_rectify_image(gip_handle h, int src_slot, int dst_slot, int interpolatio
         H_HIP(h, hipMemcpyAsync(dst->d, src->d, (size_t)cols * cn * rows, hipMemcpyDeviceToDevice, st));   // tight pitches
     } else {
         const int i = left ? 0 : 1;
-        rc = gipk_remap_u8((const uint8_t*)src->d, src->pitch, cols, rows, (uint8_t*)dst->d, dst->pitch, cols, rows, cn, h->d_map1[i], h->d_map2[i], 1, 0, 0, st);
+        rc = gipk_remap_u8_interp((const uint8_t*)src->d, src->pitch, cols, rows, (uint8_t*)dst->d, dst->pitch, cols, rows, cn, h->d_map1[i], h->d_map2[i], interpolation, 1, 0,
+                                  0, st);
         if (rc != GIP_OK) return propagate(h, rc, "rectifyImage");
     }
     if ((rc = end_read(h, src, st)) != GIP_OK) return rc;

@@ -129,7 +129,7 @@ __global__ void k_mono16_to_mono8(const uint16_t* __restrict__ src, size_t sp, u
 // Gather kernel: 6 B/px of map traffic + 4 taps (L2/L1 hits for mild distortion) + CN B/px store.
 template <int CN>
 __global__ void k_remap(const uint8_t* __restrict__ src, size_t sp, int sw, int sh, uint8_t* __restrict__ dst, size_t dp, int w, int h,
-                        const int16_t* __restrict__ map1, const uint16_t* __restrict__ map2, size_t sbs, size_t dbs)
+                        const int16_t* __restrict__ map1, const uint16_t* __restrict__ map2, size_t sbs, size_t dbs, int nearest)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
@@ -142,6 +142,14 @@ __global__ void k_remap(const uint8_t* __restrict__ src, size_t sp, int sw, int 
     bool y0 = (unsigned)sy < (unsigned)sh, y1 = (unsigned)(sy + 1) < (unsigned)sh;
     const uint8_t* s = src + blockIdx.z * sbs;
     uint8_t* d = dst + blockIdx.z * dbs + (size_t)y * dp + (size_t)x * CN;
+    if (nearest) {
+        // cv::remap INTER_NEAREST on fixed-point maps rounds the 5-bit fractions half-up (NNDeltaTab_i)
+        const int nx = sx + (ax >= 16), ny = sy + (ay >= 16);
+        const bool in = (unsigned)nx < (unsigned)sw && (unsigned)ny < (unsigned)sh;
+#pragma unroll
+        for (int k = 0; k < CN; k++) d[k] = in ? s[(size_t)ny * sp + nx * CN + k] : (uint8_t)0;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < CN; k++) {
         int p00 = (x0 && y0) ? s[(size_t)sy * sp + sx * CN + k] : 0;
@@ -312,12 +320,20 @@ int gipk_cvt_mono16_to_mono8(const uint16_t* src, size_t src_pitch, uint8_t* dst
 int gipk_remap_u8(const uint8_t* src, size_t src_pitch, int sw, int sh, uint8_t* dst, size_t dst_pitch, int w, int h, int cn, const int16_t* map1,
                   const uint16_t* map2, int batch, size_t sbs, size_t dbs, gip_stream stream)
 {
+    return gipk_remap_u8_interp(src, src_pitch, sw, sh, dst, dst_pitch, w, h, cn, map1, map2, GIP_INTER_LINEAR, batch, sbs, dbs, stream);
+}
+
+int gipk_remap_u8_interp(const uint8_t* src, size_t src_pitch, int sw, int sh, uint8_t* dst, size_t dst_pitch, int w, int h, int cn, const int16_t* map1,
+                         const uint16_t* map2, int interpolation, int batch, size_t sbs, size_t dbs, gip_stream stream)
+{
+    if (interpolation != GIP_INTER_LINEAR && interpolation != GIP_INTER_NEAREST) return GIP_ERR_UNSUPPORTED;
+    const int nearest = interpolation == GIP_INTER_NEAREST;
     GIPK_ARGCHECK(src && dst && map1 && map2 && w > 0 && h > 0 && sw > 0 && sh > 0 && batch > 0 && (cn == 1 || cn == 3));
     GIPK_ARGCHECK(((uintptr_t)map1 & 3) == 0 && ((uintptr_t)map2 & 1) == 0);
     if (cn == 1)
-        hipLaunchKernelGGL(k_remap<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs);
+        hipLaunchKernelGGL(k_remap<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
     else
-        hipLaunchKernelGGL(k_remap<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs);
+        hipLaunchKernelGGL(k_remap<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }

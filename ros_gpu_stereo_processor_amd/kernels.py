@@ -75,7 +75,7 @@ def mono16_to_mono8(src):
     return _cvt("gipk_cvt_mono16_to_mono8", src, 1, torch.uint8, src_nd=2)
 
 
-def remap(src, map1, map2):
+def remap(src, map1, map2, interpolation=capi.INTER_LINEAR):
     """src (B,H,W) or (B,H,W,3) uint8; map1 (h,w,2) int16; map2 (h,w) int16-bit-pattern of uint16."""
     L = capi.lib()
     cn = 3 if (src.dim() == 4 or (src.dim() == 3 and src.shape[-1] == 3 and map1.shape[1] != src.shape[-1])) else 1
@@ -83,8 +83,8 @@ def remap(src, map1, map2):
     sh, sw = s.shape[1], s.shape[2]
     h, w = map2.shape
     dst = torch.empty((B, h, w) if cn == 1 else (B, h, w, 3), dtype=torch.uint8, device=s.device)
-    _ck(L.gipk_remap_u8(s.data_ptr(), sw * cn, sw, sh, dst.data_ptr(), w * cn, w, h, cn, map1.data_ptr(), map2.data_ptr(), B, sh * sw * cn, h * w * cn,
-                        _stream()))
+    _ck(L.gipk_remap_u8_interp(s.data_ptr(), sw * cn, sw, sh, dst.data_ptr(), w * cn, w, h, cn, map1.data_ptr(), map2.data_ptr(), interpolation, B,
+                               sh * sw * cn, h * w * cn, _stream()))
     return dst if src.dim() == (3 if cn == 1 else 4) else dst[0]
 
 
