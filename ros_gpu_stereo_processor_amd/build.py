@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libgpuimageproc_hip.so")
-SOURCES = ["k_image.hip", "k_stereobm.hip", "k_stereobm_c4.hip", "k_post.hip", "gip_capi.hip", "gip_model.cpp"]
+SOURCES = ["k_image.hip", "k_stereobm.hip", "k_stereobm_c4.hip", "k_stereobm_wide.hip", "k_post.hip", "gip_capi.hip", "gip_model.cpp"]
 HEADERS = [os.path.join(CSRC, "gip_internal.h"), os.path.join(CSRC, "gip_model.h"), os.path.join(CSRC, "bm_common.h"), os.path.join(ROOT, "include", "gpuimageproc_hip.h")]
 ARCH = os.environ.get("GIP_OFFLOAD_ARCH", "gfx950")
 # -ffp-contract=off: the float/double paths (disparity->f32, reprojection, colour ramp, remap tables) must round

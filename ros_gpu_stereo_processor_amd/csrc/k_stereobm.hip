@@ -459,8 +459,10 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     if (rc != GIP_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const GipBmGeom g = gip_bm_geom(w, h, p);
-    // u16 window sums: 2*cap*block^2 must stay below 65536 (also keeps the poison value 0xFFFF unreachable)
-    if ((long)2 * p->prefilter_cap * p->block_size * p->block_size >= 65535 || p->num_disparities > 4096) return GIP_ERR_UNSUPPORTED;
+    // u16 window sums need 2*cap*block^2 < 65535 (which also keeps the poison value 0xFFFF unreachable); wider windows take
+    // the 32-bit fallback matcher
+    const bool wide = (long)2 * p->prefilter_cap * p->block_size * p->block_size >= 65535;
+    if (p->num_disparities > 4096) return GIP_ERR_UNSUPPORTED;
 
     if (!skip_fill) {
         hipLaunchKernelGGL(k_fill_i16, dim3(gip_div_up(w, 256), h, batch), dim3(256), 0, st, disp, disp_pitch / 2, w, h, g.filtered, disp_bstride);
@@ -476,6 +478,7 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     a.disp = disp; a.dpitch = disp_pitch / 2; a.cost = cost; a.cpitch = cost ? cost_pitch / 4 : 0;
     a.img_bs = img_bstride; a.disp_bs = disp_bstride; a.cost_bs = cost_bstride; a.filtered = g.filtered;
     a.cbeg = a.cend = a.nleft = a.nright = 0; a.TC = 64;
+    if (wide) return gip_bm_wide_launch(a, g.roi_h, batch, st);
 
     const int r = g.wsz2, nrows = g.roi_h;
     // interior columns: the whole window is un-clamped for c in [r, width1 - r)

@@ -191,9 +191,9 @@ def test_stereobm_degenerate_and_errors(gpu, oracle):
     for bad in (dict(block_size=4), dict(block_size=41), dict(num_disparities=20), dict(prefilter_cap=64), dict(texture_threshold=-1)):
         with pytest.raises(capi.GipError):
             K.stereobm(_t(l, gpu), _t(r, gpu), K.bm_params(**{**dict(block_size=5, num_disparities=16), **bad}))
-    with pytest.raises(capi.GipError) as e:  # u16 cost range exceeded -> explicit UNSUPPORTED, never a silent wrong answer
+    with pytest.raises(capi.GipError) as e:  # beyond the implemented range -> explicit UNSUPPORTED, never a silent wrong answer
         big = synth.rectified_pair(200, 120, 16, seed=4)
-        K.stereobm(_t(big[0], gpu), _t(big[1], gpu), K.bm_params(block_size=51, num_disparities=16))
+        K.stereobm(_t(big[0], gpu), _t(big[1], gpu), K.bm_params(block_size=9, num_disparities=4112))
     assert e.value.status == capi.ERR_UNSUPPORTED
 
 

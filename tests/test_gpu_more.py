@@ -39,3 +39,17 @@ def test_processor_rectify_nearest(gpu, oracle, kitchen, calib, calib_files):
     with pytest.raises(capi.GipError):
         p.rectifyImage(P.L_RAW, P.L_RECT_MONO, 2)  # INTER_CUBIC: not implemented
     p.close()
+
+
+@pytest.mark.parametrize("w,h,nd,block,cap,mind,d12", [(320, 96, 32, 33, 31, 0, 1), (400, 120, 64, 51, 31, 0, -1), (300, 80, 16, 23, 63, 0, 1),
+                                                        (520, 300, 48, 255, 31, 0, 0), (260, 90, 32, 41, 63, -8, 1)])
+def test_wide_window_fallback(gpu, oracle, w, h, nd, block, cap, mind, d12):
+    """windows whose SAD exceeds 16 bits (cv::StereoBM allows block up to 255, cap up to 63): 32-bit fallback matcher"""
+    from ros_gpu_stereo_processor_amd import kernels as K, synth
+    l, r, _ = synth.rectified_pair(w, h, max(16, min(nd, w // 4)), seed=w + block)
+    kw = dict(block_size=block, num_disparities=nd, prefilter_cap=cap, min_disparity=mind, texture_threshold=10, uniqueness_ratio=10, disp12_max_diff=d12)
+    exp = oracle.stereobm(l, r, oracle.bm_params(**kw))
+    got = K.stereobm(_t(l, gpu), _t(r, gpu), K.bm_params(**kw)).cpu().numpy()
+    assert np.array_equal(got, exp)
+    if block < min(w, h) // 2:
+        assert (exp != (mind - 1) * 16).any()
