@@ -167,6 +167,54 @@ bool find_matrix(const std::string& text, const std::string& key, std::vector<do
 
 }  // namespace
 
+// camera_calibration_parsers INI layout ("# oST version 5.0 parameters"):
+//   [image] / width / <n> / height / <n> / [<camera name>] / camera matrix / 3x3 / distortion / 1xN / rectification / 3x3 / projection / 3x4
+static bool ini_numbers_after(const std::string& text, const std::string& label, size_t max_count, std::vector<double>& out)
+{
+    size_t pos = text.find(label);
+    if (pos == std::string::npos) return false;
+    std::istringstream ss(text.substr(pos + label.size()));
+    out.clear();
+    std::string tok;
+    while (out.size() < max_count && ss >> tok) {
+        char* end = nullptr;
+        double v = std::strtod(tok.c_str(), &end);
+        if (end == tok.c_str() || *end != '\0') break;   // next label or section
+        out.push_back(v);
+    }
+    return !out.empty();
+}
+
+static int parse_calibration_ini(const std::string& path, const std::string& text, gip_camera_info& out, std::string& camera_name, std::string& err)
+{
+    std::memset(&out, 0, sizeof out);
+    std::vector<double> d;
+    if (!ini_numbers_after(text, "width", 1, d)) { err = "width missing in " + path; return GIP_ERR_IO; }
+    out.width = (int)d[0];
+    if (!ini_numbers_after(text, "height", 1, d)) { err = "height missing in " + path; return GIP_ERR_IO; }
+    out.height = (int)d[0];
+    camera_name.clear();
+    size_t pos = 0;
+    while ((pos = text.find('[', pos)) != std::string::npos) {   // the section that is not [image] names the camera
+        size_t e = text.find(']', pos);
+        if (e == std::string::npos) break;
+        std::string sec = text.substr(pos + 1, e - pos - 1);
+        if (sec != "image") { camera_name = sec; break; }
+        pos = e + 1;
+    }
+    if (!ini_numbers_after(text, "camera matrix", 9, d) || d.size() != 9) { err = "camera matrix malformed in " + path; return GIP_ERR_IO; }
+    std::memcpy(out.K, d.data(), sizeof out.K);
+    if (!ini_numbers_after(text, "distortion", 8, d)) { err = "distortion malformed in " + path; return GIP_ERR_IO; }
+    out.nD = (int)d.size();
+    for (size_t i = 0; i < d.size(); i++) out.D[i] = d[i];
+    if (!ini_numbers_after(text, "rectification", 9, d) || d.size() != 9) { err = "rectification malformed in " + path; return GIP_ERR_IO; }
+    std::memcpy(out.R, d.data(), sizeof out.R);
+    if (!ini_numbers_after(text, "projection", 12, d) || d.size() != 12) { err = "projection malformed in " + path; return GIP_ERR_IO; }
+    std::memcpy(out.P, d.data(), sizeof out.P);
+    return GIP_OK;
+}
+
+// camera_calibration_parsers::readCalibration picks the format by extension (.ini, .yml/.yaml)
 int gip_parse_calibration_yaml(const std::string& path, gip_camera_info& out, std::string& camera_name, std::string& err)
 {
     std::ifstream f(path);
@@ -174,6 +222,7 @@ int gip_parse_calibration_yaml(const std::string& path, gip_camera_info& out, st
     std::stringstream buf;
     buf << f.rdbuf();
     const std::string text = buf.str();
+    if (path.size() >= 4 && path.compare(path.size() - 4, 4, ".ini") == 0) return parse_calibration_ini(path, text, out, camera_name, err);
     std::memset(&out, 0, sizeof out);
     std::string v;
     if (!find_scalar(text, "image_width", v)) { err = "image_width missing in " + path; return GIP_ERR_IO; }

@@ -72,3 +72,19 @@ def test_calibration_yaml_reader(built_lib, calib_files, calib):
         assert np.array_equal(np.array(ci.D[:5]), calib[side]["D"])
         assert np.array_equal(np.array(ci.R[:]), calib[side]["R"])
         assert np.array_equal(np.array(ci.P[:]), calib[side]["P"])
+
+
+def test_calibration_ini_reader(built_lib, calib, tmp_path):
+    """camera_calibration_parsers' INI layout (readCalibration picks the parser by extension)"""
+    from ros_gpu_stereo_processor_amd import processor as P
+    import numpy as np
+    c = calib["left"]
+    fmt = lambda a, n: "\n".join(" ".join("%.6f" % v for v in a[i:i + n]) for i in range(0, len(a), n))  # noqa: E731
+    text = ("# oST version 5.0 parameters\n\n\n[image]\n\nwidth\n752\n\nheight\n480\n\n[narrow_stereo/left]\n\ncamera matrix\n%s\n\ndistortion\n%s\n\n"
+            "rectification\n%s\n\nprojection\n%s\n\n" % (fmt(c["K"], 3), fmt(c["D"], 5), fmt(c["R"], 3), fmt(c["P"], 4)))
+    path = tmp_path / "left.ini"
+    path.write_text(text)
+    ci, name = P.read_calibration(str(path))
+    assert (ci.width, ci.height, ci.nD, name) == (752, 480, 5, "narrow_stereo/left")
+    assert np.array_equal(np.array(ci.K[:]), c["K"]) and np.array_equal(np.array(ci.D[:5]), c["D"])
+    assert np.array_equal(np.array(ci.R[:]), c["R"]) and np.array_equal(np.array(ci.P[:]), c["P"])
