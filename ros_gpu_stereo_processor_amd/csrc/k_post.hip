@@ -90,38 +90,84 @@ __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, f
 // size <= maxSpeckleSize.  Components of a fixed symmetric graph => order independent => a parallel union-find gives
 // the same result bit for bit.
 //
-// Run-based CCL (the union-find nodes are horizontal RUNS, not pixels, so the number of global atomics scales with the
-// number of run overlaps instead of the number of pixels):
-//   k_spk_runs   one workgroup per image row: every valid pixel gets the COLUMN of the first pixel of its run (u16, the only
-//                dense scratch array; segmented max-scan in LDS); run starts initialise their union-find node (parent =
-//                self, size 0); the last pixel of a run stores the run length at the start
-//   k_spk_merge  one union per maximal overlap segment between runs of adjacent rows (atomicMin union-find on run starts)
-//   k_spk_sizes  every run start: root = find(); atomicAdd(size[root], run length); path compression
-//   k_spk_apply  pixels whose component has <= maxSpeckleSize pixels become newVal
-__device__ __forceinline__ int uf_find(int* lab, int i)
+// Run-based, two-level CCL.  The union-find nodes are horizontal RUNS, not pixels; node id = y * w + (ordinal of the run in
+// its row).  Only ONE kernel touches every pixel, and most unions happen in LDS:
+//   k_spk_scan   one WAVEFRONT per image row, marching over it 64 columns at a time with ballots (no LDS, no barrier, no
+//                atomics): run ordinal of every pixel (ord16, u16, the only dense scratch array), the row's run list
+//                (start column | length << 16, indexed by ordinal) and the row's vertical joins -- one per maximal overlap
+//                segment between a run of row y and a run of row y+1 -- appended to a compact per-row list
+//   k_spk_strip  one workgroup per strip of SPK_STRIP rows: union-find over the strip's runs in LDS, component sizes
+//                accumulated at the strip-local roots; writes parent (= local root) and size (at local roots, else 0)
+//   k_spk_cross  one wavefront per strip boundary row: global atomicMin union-find over the joins that cross strips
+//   k_spk_sizes  strip-local roots that lost their root status add their size to the global root (+ path compression)
+//   k_spk_apply  one wavefront per row: runs whose component has <= maxSpeckleSize pixels are overwritten with newVal
+// Why: only ~1 % of the pixels start a union or close a run, but each of those is a chain of dependent memory round trips.
+// With one thread per pixel about every second wavefront holds one such lane and stays resident for microseconds (0.19 ms
+// for merge and for sizes on 64 x 1242x375 maps); and thousands of simultaneous global unions build trees as deep as the
+// image is tall.  Lists make the slow path dense; the LDS level makes it short.
+constexpr int SPK_STRIP = 32;        // rows per strip
+constexpr int SPK_CAP = 7168;        // runs per strip the LDS level can hold (else the strip is merged globally)
+constexpr int SPK_TPB = 256;
+
+__device__ __forceinline__ int uf_find(int* nd, int i)
 {
     // agent-scope relaxed loads: other workgroups (other XCDs) relink concurrently; a stale parent is still an
     // ancestor, so the loop terminates, and the union below only trusts what the atomic returns.
-    int p = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Path halving on the way up: parents only ever decrease (links go to the smaller index), so lowering nd[i] to its
+    // grandparent with an atomic min keeps "nd[i] is an ancestor of i" whatever else happens concurrently.
+    int p = __hip_atomic_load(&nd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != i) {
+        const int gp = __hip_atomic_load(&nd[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p) __hip_atomic_fetch_min(&nd[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         i = p;
-        p = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p = gp;
     }
     return i;
 }
 
-__device__ __forceinline__ void uf_union(int* lab, int a, int b)
+__device__ __forceinline__ void uf_union(int* nd, int a, int b)
 {
     bool done;
     do {
-        a = uf_find(lab, a);
-        b = uf_find(lab, b);
+        a = uf_find(nd, a);
+        b = uf_find(nd, b);
         if (a < b) {
-            int old = atomicMin(&lab[b], a);
+            int old = atomicMin(&nd[b], a);
             done = (old == b);
             b = old;
         } else if (b < a) {
-            int old = atomicMin(&lab[a], b);
+            int old = atomicMin(&nd[a], b);
+            done = (old == a);
+            a = old;
+        } else {
+            done = true;
+        }
+    } while (!done);
+}
+
+// the same on an LDS array (workgroup scope)
+__device__ __forceinline__ int lds_find(int* nd, int i)
+{
+    int p = __hip_atomic_load(&nd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (p != i) {
+        i = p;
+        p = __hip_atomic_load(&nd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return i;
+}
+
+__device__ __forceinline__ void lds_union(int* nd, int a, int b)
+{
+    bool done;
+    do {
+        a = lds_find(nd, a);
+        b = lds_find(nd, b);
+        if (a < b) {
+            int old = __hip_atomic_fetch_min(&nd[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            int old = __hip_atomic_fetch_min(&nd[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             done = (old == a);
             a = old;
         } else {
@@ -136,102 +182,195 @@ __device__ __forceinline__ bool spk_conn(int a, int b, int new_val, int max_diff
     return a != new_val && b != new_val && (df < 0 ? -df : df) <= max_diff;
 }
 
-constexpr int SPK_TPB = 256;
+// Scratch: parent / csize (int32, indexed by node id, filled from the front of every row's w slots), runlist / joinlist
+// (u32, same indexing), ord16 (u16 per pixel), nrun / njoin (per row), global_strip (per strip: 1 = merged globally).
+struct SpkScratch {
+    int* parent;
+    int* csize;
+    u32* runlist;
+    u32* joinlist;
+    unsigned short* ord16;
+    int* nrun;
+    int* njoin;
+    int* global_strip;
+};
 
-// Scratch per pixel: start16 (u16: column of the pixel's run start, 0xFFFF = invalid pixel) is the only DENSE array;
-// parent / rlen / csize (int32) are touched only at run-start pixels.
-__global__ void __launch_bounds__(SPK_TPB) k_spk_runs(const int16_t* __restrict__ disp, size_t dpitch, unsigned short* __restrict__ start16,
-                                                       int* __restrict__ parent, int* __restrict__ rlen, int* __restrict__ csize, int w, int h, int new_val,
-                                                       int max_diff, size_t dbs)
+__global__ void __launch_bounds__(64) k_spk_scan(const int16_t* __restrict__ disp, size_t dpitch, SpkScratch S, int w, int h, int new_val,
+                                                  int max_diff, size_t dbs)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-    short* row = (short*)smem_raw;                 // w values (+1 pad)
-    int* part = (int*)(smem_raw + (((size_t)w * 2 + 2 + 15) & ~(size_t)15));  // SPK_TPB partial maxima
-    const int y = blockIdx.x, t = threadIdx.x;
-    const int16_t* d = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
-    const size_t base = blockIdx.z * (size_t)w * h + (size_t)y * w;
-    for (int x = t; x < w; x += SPK_TPB) row[x] = d[x];
-    __syncthreads();
-    const int chunk = (w + SPK_TPB - 1) / SPK_TPB;
-    const int x0 = t * chunk, x1 = min(x0 + chunk, w);
-    // pass 1: last run start inside my chunk
-    int last = -1;
-    for (int x = x0; x < x1; x++) {
-        int v = row[x];
-        bool start = v != new_val && (x == 0 || !spk_conn(row[x - 1], v, new_val, max_diff));
-        if (start) last = x;
-    }
-    part[t] = last;
-    __syncthreads();
-    // inclusive max-scan over the partials (Hillis-Steele, 8 steps)
-    for (int off = 1; off < SPK_TPB; off <<= 1) {
-        int v = part[t];
-        int o = t >= off ? part[t - off] : -1;
-        __syncthreads();
-        part[t] = v > o ? v : o;
-        __syncthreads();
-    }
-    int running = t > 0 ? part[t - 1] : -1;
-    // pass 2: run start of every pixel; run starts initialise their union-find node, the run's last pixel stores its length
-    for (int x = x0; x < x1; x++) {
-        int v = row[x];
-        bool valid = v != new_val;
-        bool start = valid && (x == 0 || !spk_conn(row[x - 1], v, new_val, max_diff));
-        if (start) {
-            running = x;
-            parent[base + x] = y * w + x;
-            csize[base + x] = 0;
-        }
-        start16[base + x] = valid ? (unsigned short)running : (unsigned short)0xFFFFu;
-        bool last_of_run = valid && (x == w - 1 || !spk_conn(v, row[x + 1], new_val, max_diff));
-        if (last_of_run) rlen[base + running] = x - running + 1;
-    }
-}
-
-__global__ void k_spk_merge(const int16_t* __restrict__ disp, size_t dpitch, const unsigned short* __restrict__ start16, int* __restrict__ parent,
-                            int w, int h, int new_val, int max_diff, size_t dbs)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y + 1 >= h) return;
+    const int y = blockIdx.x, lane = threadIdx.x;
     const int16_t* d0 = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
     const int16_t* d1 = d0 + dpitch;
-    int a = d0[x], b = d1[x];
-    if (!spk_conn(a, b, new_val, max_diff)) return;
-    if (x > 0) {
-        // the pair (x-1) already joins the same two runs: this vertical edge is redundant
-        int al = d0[x - 1], bl = d1[x - 1];
-        if (spk_conn(al, a, new_val, max_diff) && spk_conn(bl, b, new_val, max_diff) && spk_conn(al, bl, new_val, max_diff)) return;
+    const bool has_next = y + 1 < h;
+    const size_t base = blockIdx.z * (size_t)w * h + (size_t)y * w;
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= me
+    const unsigned long long lt = le >> 1;                                           // lanes <  me
+    int n_run = 0, n_join = 0, carry_start = 0;
+    for (int c0 = 0; c0 < w; c0 += 64) {
+        const int x = c0 + lane;
+        const bool in = x < w;
+        const int v = in ? d0[x] : new_val;
+        const int vl = (in && x > 0) ? d0[x - 1] : new_val;
+        const int vr = (x + 1 < w) ? d0[x + 1] : new_val;
+        const int b = (in && has_next) ? d1[x] : new_val;
+        const int bl = (in && has_next && x > 0) ? d1[x - 1] : new_val;
+        const bool valid = v != new_val;
+        const bool cl = spk_conn(vl, v, new_val, max_diff);   // joined to the left neighbour
+        const unsigned long long smask = __ballot(valid && !cl);
+        const unsigned long long m = smask & le;
+        const int ord = n_run + __popcll(m) - 1;
+        const int rs = m ? (c0 + 63 - __builtin_clzll(m)) : carry_start;
+        if (in) S.ord16[base + x] = valid ? (unsigned short)ord : (unsigned short)0xFFFFu;
+        if (valid && !spk_conn(v, vr, new_val, max_diff))          // last pixel of its run (vr = new_val past the row end)
+            S.runlist[base + ord] = (u32)rs | ((u32)(x - rs + 1) << 16);   // length <= w <= 32768
+        // vertical join, unless the pair (x-1) already joins the same two runs
+        const bool join = spk_conn(v, b, new_val, max_diff) && !(cl && spk_conn(bl, b, new_val, max_diff) && spk_conn(vl, bl, new_val, max_diff));
+        const unsigned long long jmask = __ballot(join);
+        if (join) S.joinlist[base + n_join + __popcll(jmask & lt)] = (u32)ord | ((u32)x << 16);
+        n_join += __popcll(jmask);
+        n_run += __popcll(smask);
+        carry_start = __shfl(rs, 63);
     }
-    const size_t base = blockIdx.z * (size_t)w * h;
-    const int i = y * w + x;
-    uf_union(parent + base, y * w + (int)start16[base + i], (y + 1) * w + (int)start16[base + i + w]);
+    if (lane == 0) {
+        S.nrun[blockIdx.z * (size_t)h + y] = n_run;
+        S.njoin[blockIdx.z * (size_t)h + y] = n_join;
+    }
 }
 
-__global__ void k_spk_sizes(const unsigned short* __restrict__ start16, int* __restrict__ parent, const int* __restrict__ rlen, int* __restrict__ csize,
-                            int w, int h)
+__global__ void __launch_bounds__(SPK_TPB) k_spk_strip(SpkScratch S, int w, int h, int nstrips)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const size_t base = blockIdx.z * (size_t)w * h;
-    const int i = y * w + x;
-    if ((int)start16[base + i] != x) return;   // not a run start (0xFFFF never equals a column: w <= 32768)
-    int root = parent[base + i];
-    int q = parent[base + root];
-    while (q != root) { root = q; q = parent[base + root]; }   // the merge kernel is complete: plain loads are coherent
-    parent[base + i] = root;                                    // compression: starts now point straight at their root
-    atomicAdd(&csize[base + root], rlen[base + i]);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    int* lab = (int*)smem_raw;              // SPK_CAP
+    int* lsize = lab + SPK_CAP;             // SPK_CAP
+    __shared__ int off[SPK_STRIP + 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int y0 = blockIdx.x * SPK_STRIP;
+    const int R = min(SPK_STRIP, h - y0);
+    const size_t ibase = blockIdx.z * (size_t)w * h;
+    const int* nrun = S.nrun + blockIdx.z * (size_t)h + y0;
+    const int* njoin = S.njoin + blockIdx.z * (size_t)h + y0;
+    if (t == 0) {
+        int acc = 0;
+        for (int i = 0; i < R; i++) { off[i] = acc; acc += nrun[i]; }
+        for (int i = R; i <= SPK_STRIP; i++) off[i] = acc;
+    }
+    __syncthreads();
+    const int T = off[R];
+    if (T > SPK_CAP) {
+        // too many runs for the LDS level: every run is its own strip-local root and all joins go to k_spk_cross
+        if (t == 0) S.global_strip[blockIdx.z * (size_t)nstrips + blockIdx.x] = 1;
+        for (int yl = wave; yl < R; yl += SPK_TPB / 64)
+            for (int k = lane; k < nrun[yl]; k += 64) {
+                const size_t node = ibase + (size_t)(y0 + yl) * w + k;
+                S.parent[node] = (y0 + yl) * w + k;
+                S.csize[node] = (int)(S.runlist[node] >> 16);
+            }
+        return;
+    }
+    if (t == 0) S.global_strip[blockIdx.z * (size_t)nstrips + blockIdx.x] = 0;
+    for (int i = t; i < T; i += SPK_TPB) { lab[i] = i; lsize[i] = 0; }
+    __syncthreads();
+    // joins inside the strip
+    for (int yl = wave; yl + 1 < R; yl += SPK_TPB / 64) {
+        const size_t rb = ibase + (size_t)(y0 + yl) * w;
+        const int n = njoin[yl];
+        for (int k = lane; k < n; k += 64) {
+            const u32 item = S.joinlist[rb + k];
+            const int x = (int)(item >> 16);
+            lds_union(lab, off[yl] + (int)(item & 0xFFFFu), off[yl + 1] + (int)S.ord16[rb + w + x]);
+        }
+    }
+    __syncthreads();
+    // sizes at the local roots; flatten
+    for (int yl = wave; yl < R; yl += SPK_TPB / 64) {
+        const size_t rb = ibase + (size_t)(y0 + yl) * w;
+        const int n = nrun[yl];
+        for (int k = lane; k < n; k += 64) {
+            const int i = off[yl] + k;
+            const int r = lds_find(lab, i);
+            atomicAdd(&lsize[r], (int)(S.runlist[rb + k] >> 16));
+            if (r != i) __hip_atomic_store(&lab[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // roots do not move any more
+        }
+    }
+    __syncthreads();
+    for (int yl = wave; yl < R; yl += SPK_TPB / 64) {
+        const size_t rb = ibase + (size_t)(y0 + yl) * w;
+        const int n = nrun[yl];
+        for (int k = lane; k < n; k += 64) {
+            const int i = off[yl] + k;
+            const int r = lab[i];
+            // local index -> (row, ordinal): the last row whose offset is <= r
+            int lo = 0, hi = R - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (off[mid] <= r) lo = mid; else hi = mid - 1;
+            }
+            S.parent[rb + k] = (y0 + lo) * w + (r - off[lo]);
+            S.csize[rb + k] = (r == i) ? lsize[i] : 0;
+        }
+    }
 }
 
-__global__ void k_spk_apply(int16_t* __restrict__ disp, size_t dpitch, const unsigned short* __restrict__ start16, const int* __restrict__ parent,
-                            const int* __restrict__ csize, int w, int h, int new_val, int max_size, size_t dbs)
+__global__ void __launch_bounds__(64) k_spk_cross(SpkScratch S, int w, int h, int nstrips)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const size_t base = blockIdx.z * (size_t)w * h;
-    const unsigned s = start16[base + y * w + x];
-    if (s == 0xFFFFu) return;
-    const int root = parent[base + y * w + (int)s];   // a start's entry holds its root (k_spk_sizes compressed it)
-    if (csize[base + root] <= max_size) ((int16_t*)((uint8_t*)disp + blockIdx.z * dbs))[(size_t)y * dpitch + x] = (int16_t)new_val;
+    const int y = blockIdx.x;                       // joins between rows y and y+1
+    if (((y + 1) % SPK_STRIP) != 0 && !S.global_strip[blockIdx.z * (size_t)nstrips + y / SPK_STRIP]) return;
+    const size_t ibase = blockIdx.z * (size_t)w * h;
+    const size_t rb = ibase + (size_t)y * w;
+    const int n = S.njoin[blockIdx.z * (size_t)h + y];
+    for (int k = threadIdx.x; k < n; k += 64) {
+        const u32 item = S.joinlist[rb + k];
+        const int x = (int)(item >> 16);
+        uf_union(S.parent + ibase, y * w + (int)(item & 0xFFFFu), (y + 1) * w + (int)S.ord16[rb + w + x]);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_spk_sizes(SpkScratch S, int w, int h)
+{
+    const int y = blockIdx.x;
+    const size_t ibase = blockIdx.z * (size_t)w * h;
+    const int n = S.nrun[blockIdx.z * (size_t)h + y];
+    int* nd = S.parent + ibase;
+    for (int k = threadIdx.x; k < n; k += 64) {
+        const int i = y * w + k;
+        const int sz = S.csize[ibase + i];
+        if (sz == 0) continue;                          // not a strip-local root
+        int root = nd[i];
+        if (root == i) continue;                        // still a root: its size stays where it is
+        int q = nd[root];
+        while (q != root) { root = q; q = nd[root]; }   // k_spk_cross is complete: plain loads are coherent
+        nd[i] = root;                                   // compression: local roots now point straight at the global root
+        atomicAdd(&S.csize[ibase + root], sz);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_spk_apply(int16_t* __restrict__ disp, size_t dpitch, SpkScratch S, int w, int h, int new_val, int max_size,
+                                                   size_t dbs)
+{
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const size_t ibase = blockIdx.z * (size_t)w * h;
+    const int n = S.nrun[blockIdx.z * (size_t)h + y];
+    int16_t* drow = (int16_t*)((uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        u32 item = 0;
+        bool kill = false;
+        if (k < n) {
+            item = S.runlist[ibase + (size_t)y * w + k];
+            const int r1 = S.parent[ibase + (size_t)y * w + k];   // strip-local root (or already the global one)
+            const int r2 = S.parent[ibase + r1];                   // k_spk_sizes left the global root in every local root
+            kill = S.csize[ibase + r2] <= max_size;
+        }
+        // the wave erases the doomed runs together (a doomed run is at most maxSpeckleSize pixels long)
+        unsigned long long m = __ballot(kill);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const u32 it = (u32)__shfl((int)item, src);
+            const int s0 = (int)(it & 0xFFFFu), len = (int)(it >> 16);
+            for (int i = lane; i < len; i += 64) drow[s0 + i] = (int16_t)new_val;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------- reprojection / cloud
@@ -372,7 +511,7 @@ int gipk_disparity_to_f32(const int16_t* disp, size_t disp_pitch, float* dst, si
     return GIP_OK;
 }
 
-size_t gipk_speckle_scratch_bytes(int w, int h, int batch) { return (size_t)w * h * batch * 14 + 64; }
+size_t gipk_speckle_scratch_bytes(int w, int h, int batch) { return (size_t)w * h * batch * 18 + (size_t)h * batch * 12 + 64; }
 
 int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff, void* scratch,
                          size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream)
@@ -381,18 +520,22 @@ int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new
     GIPK_ARGCHECK(scratch_bytes >= gipk_speckle_scratch_bytes(w, h, batch) && (size_t)w * h < (1u << 31));
     if (w > 32768) return GIP_ERR_UNSUPPORTED;
     const size_t n = (size_t)w * h * batch;
-    int* parent = (int*)gip_align_up((size_t)(uintptr_t)scratch, 16);
-    int* rlen = parent + n;
-    int* csize = rlen + n;
-    unsigned short* start16 = (unsigned short*)(csize + n);
+    const int nstrips = (h + SPK_STRIP - 1) / SPK_STRIP;
+    SpkScratch S;
+    S.parent = (int*)gip_align_up((size_t)(uintptr_t)scratch, 16);
+    S.csize = S.parent + n;
+    S.runlist = (u32*)(S.csize + n);
+    S.joinlist = S.runlist + n;
+    S.nrun = (int*)(S.joinlist + n);
+    S.njoin = S.nrun + (size_t)h * batch;
+    S.global_strip = S.njoin + (size_t)h * batch;    // nstrips * batch <= h * batch entries
+    S.ord16 = (unsigned short*)(S.global_strip + (size_t)h * batch);
     hipStream_t st = (hipStream_t)stream;
-    dim3 g = grid2d(w, h, batch);
-    size_t sh = (((size_t)w * 2 + 2 + 15) & ~(size_t)15) + SPK_TPB * sizeof(int);
-    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_spk_runs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(k_spk_runs, dim3(h, 1, batch), dim3(SPK_TPB), sh, st, disp, disp_pitch / 2, start16, parent, rlen, csize, w, h, new_val, max_diff, disp_bstride);
-    hipLaunchKernelGGL(k_spk_merge, g, dim3(TPB), 0, st, disp, disp_pitch / 2, start16, parent, w, h, new_val, max_diff, disp_bstride);
-    hipLaunchKernelGGL(k_spk_sizes, g, dim3(TPB), 0, st, start16, parent, rlen, csize, w, h);
-    hipLaunchKernelGGL(k_spk_apply, g, dim3(TPB), 0, st, disp, disp_pitch / 2, start16, parent, csize, w, h, new_val, max_speckle_size, disp_bstride);
+    hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
+    hipLaunchKernelGGL(k_spk_strip, dim3(nstrips, 1, batch), dim3(SPK_TPB), (size_t)SPK_CAP * 8, st, S, w, h, nstrips);
+    if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(64), 0, st, S, w, h, nstrips);
+    hipLaunchKernelGGL(k_spk_sizes, dim3(h, 1, batch), dim3(64), 0, st, S, w, h);
+    hipLaunchKernelGGL(k_spk_apply, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_speckle_size, disp_bstride);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }

@@ -214,6 +214,28 @@ def test_speckle_filter_bit_exact(gpu, oracle):
             assert np.array_equal(got[b], oracle.filter_speckles(batch[b], -16, max_size, max_diff)), (max_size, max_diff, b)
 
 
+def test_speckle_filter_dense_runs_and_odd_shapes(gpu, oracle):
+    """Noise maps have one run per pixel: more runs per 32-row strip than the LDS level holds, so the strip is merged by the
+    global union-find instead (k_spk_strip fallback); the half-noise map mixes both kinds of strips.  Odd shapes cover widths
+    that are not a multiple of the 64-column scan step and heights that are not a multiple of the strip."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    rng = np.random.default_rng(77)
+    noise = (rng.integers(0, 6, (100, 640)) * 16).astype(np.int16)           # 32 x 640 runs per strip > 7168
+    half = noise.copy()
+    half[40:, :] = (7 * 16 + (np.arange(640) // 40)[None, :]).astype(np.int16)
+    half[50:58, 100:104] = -16
+    snake = np.full((70, 257), -16, np.int16)                                 # one component as deep as the image
+    snake[::2, :] = 48
+    snake[1::4, 0] = 48
+    snake[3::4, 256] = 48
+    for name, img, args in (("noise", noise, (3, 16)), ("noise0", noise, (5, 0)), ("half", half, (30, 16)), ("snake", snake, (100000, 0)),
+                            ("snake_small", snake, (100, 0)), ("row", noise[:1, :300].copy(), (2, 16)), ("col", noise[:, :1].copy(), (2, 16)),
+                            ("px", noise[:1, :1].copy(), (1, 0)), ("w65", noise[:33, :65].copy(), (4, 16))):
+        exp = oracle.filter_speckles(img, -16, *args)
+        got = _n(K.filter_speckles(_t(img[None].copy(), gpu), -16, *args))[0]
+        assert np.array_equal(got, exp), name
+
+
 def test_speckle_on_real_disparity(gpu, oracle, kitchen):
     from ros_gpu_stereo_processor_amd import kernels as K
     d = oracle.stereobm(kitchen["left_rect"], kitchen["right_rect"], oracle.bm_params(block_size=15, num_disparities=64))

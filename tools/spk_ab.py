@@ -24,7 +24,7 @@ def run(i, d):
     assert rc == 0, rc
 for i in range(len(libs)):
     d = d0.clone(); run(i, d); torch.cuda.synchronize(); outs.append(d)
-print("outputs identical:", all(bool(torch.equal(outs[0], o)) for o in outs[1:]), " changed px:", int((outs[0] != d0).sum()))
+print("outputs identical:", [bool(torch.equal(outs[0], o)) for o in outs[1:]], " changed px:", int((outs[0] != d0).sum()))
 times = [[] for _ in libs]
 for rnd in range(10):
     for i in range(len(libs)):
