@@ -25,6 +25,8 @@ struct BmArgs {
 // k_stereobm_c4.hip: column-sum matcher for the interior columns.  Returns GIP_OK and sets *handled when a kernel
 // instantiation exists for (ndisp, block radius); otherwise leaves *handled false and launches nothing.
 int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled);
+// true when gip_bm_c4_launch would handle these arguments (nothing is launched)
+bool gip_bm_c4_can(const BmArgs& a);
 
 // k_stereobm_wide.hip: 32-bit fallback for windows with 2*cap*block^2 >= 65535, all output columns
 int gip_bm_wide_launch(const BmArgs& a, int nrows, int batch, hipStream_t st);

@@ -161,6 +161,62 @@ __global__ void k_remap(const uint8_t* __restrict__ src, size_t sp, int sw, int 
     }
 }
 
+// Mono, 4 pixels per thread (same column, 4 consecutive rows).  A gather kernel like this one is latency bound, not
+// bandwidth bound: its time is (waves / resident wave slots) x (map load -> tap load round trip).  Four pixels per thread
+// issue 8 map loads and then 16 taps back to back, so a quarter of the waves pay the same two round trips.  The lanes of a
+// wave stay on ADJACENT columns: every load instruction still touches one or two cache lines (4 adjacent columns per lane
+// were measured 30 % slower than the scalar kernel: 4x the lines per instruction).
+#ifndef RM_ROWS_N
+#define RM_ROWS_N 4
+#endif
+constexpr int RM_ROWS = RM_ROWS_N;
+__global__ void k_remap_r4(const uint8_t* __restrict__ src, size_t sp, int sw, int sh, uint8_t* __restrict__ dst, size_t dp, int w, int h,
+                           const int16_t* __restrict__ map1, const uint16_t* __restrict__ map2, size_t sbs, size_t dbs, int nearest)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = (blockIdx.y * blockDim.y + threadIdx.y) * RM_ROWS;
+    if (x >= w || y0 >= h) return;
+    int sx[RM_ROWS], sy[RM_ROWS], fr[RM_ROWS];
+#pragma unroll
+    for (int j = 0; j < RM_ROWS; j++) {
+        const int yy = min(y0 + j, h - 1);
+        const size_t o = (size_t)yy * w + x;
+        const short2 t = ((const short2*)map1)[o];
+        sx[j] = t.x;
+        sy[j] = t.y;
+        fr[j] = map2[o] & 1023;
+    }
+    const uint8_t* s = src + blockIdx.z * sbs;
+    uint8_t* d = dst + blockIdx.z * dbs + (size_t)y0 * dp + x;
+    if (nearest) {
+#pragma unroll
+        for (int j = 0; j < RM_ROWS; j++) {
+            const int nx = sx[j] + ((fr[j] & 31) >= 16), ny = sy[j] + ((fr[j] >> 5) >= 16);
+            const bool in = (unsigned)nx < (unsigned)sw && (unsigned)ny < (unsigned)sh;
+            const uint8_t v = in ? s[(size_t)ny * sp + nx] : (uint8_t)0;
+            if (y0 + j < h) d[(size_t)j * dp] = v;
+        }
+        return;
+    }
+    int p[RM_ROWS][4];
+#pragma unroll
+    for (int j = 0; j < RM_ROWS; j++) {
+        const bool bx0 = (unsigned)sx[j] < (unsigned)sw, bx1 = (unsigned)(sx[j] + 1) < (unsigned)sw;
+        const bool by0 = (unsigned)sy[j] < (unsigned)sh, by1 = (unsigned)(sy[j] + 1) < (unsigned)sh;
+        const uint8_t* q = s + (ptrdiff_t)sy[j] * (ptrdiff_t)sp + sx[j];
+        p[j][0] = (bx0 && by0) ? q[0] : 0;
+        p[j][1] = (bx1 && by0) ? q[1] : 0;
+        p[j][2] = (bx0 && by1) ? q[sp] : 0;
+        p[j][3] = (bx1 && by1) ? q[sp + 1] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < RM_ROWS; j++) {
+        const int ax = fr[j] & 31, ay = fr[j] >> 5;
+        const int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
+        const int v = (p[j][0] * w00 + p[j][1] * w01 + p[j][2] * w10 + p[j][3] * w11 + 16384) >> 15;
+        if (y0 + j < h) d[(size_t)j * dp] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- prefilters
 // XSOBEL: 3x3 Sobel-x with reflect-101 rows, columns 0 / w-1 and (odd h) the last row forced to cap.
 __global__ void k_prefilter_xsobel(const uint8_t* __restrict__ src, size_t sp, uint8_t* __restrict__ dst, size_t dp, int w, int h, int cap,
@@ -178,49 +234,60 @@ __global__ void k_prefilter_xsobel(const uint8_t* __restrict__ src, size_t sp, u
     *d = (uint8_t)(clampi(v, -cap, cap) + cap);
 }
 
-// XSOBEL, 4 pixels per thread: three aligned dwords per source row (previous / own / next quad) and one dword store.
+// XSOBEL, 4 columns x XS_ROWS rows per thread: per source row three aligned dwords (previous / own / next quad) give the four
+// horizontal differences; the rows roll through the 1-2-1 vertical sum, so XS_ROWS + 2 rows are read for XS_ROWS rows written
+// (one dword store each).  Like every streaming pass here it is bound by (waves / wave slots) x load latency, hence the
+// 16 pixels per thread with all loads of a row issued together.
 // Requires 4-byte aligned rows (base, pitch, batch stride); the launcher falls back to the scalar kernel otherwise.
+#ifndef XS_ROWS_N
+#define XS_ROWS_N 4
+#endif
+constexpr int XS_ROWS = XS_ROWS_N;
 __global__ void k_prefilter_xsobel_v4(const uint8_t* __restrict__ src, size_t sp, uint8_t* __restrict__ dst, size_t dp, int w, int h, int cap,
                                       size_t sbs, size_t dbs)
 {
-    const int xq = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int xq = blockIdx.x * blockDim.x + threadIdx.x, yb = (blockIdx.y * blockDim.y + threadIdx.y) * XS_ROWS;
     const int x0 = xq * 4;
-    if (x0 >= w || y >= h) return;
+    if (x0 >= w || yb >= h) return;
     const int nq = (int)(sp >> 2);                      // dwords per source row
-    uint32_t out;
-    if ((h & 1) && y == h - 1) {
-        out = (uint32_t)cap * 0x01010101u;
-    } else {
-        const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0);
-        const int yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-        const uint8_t* s = src + blockIdx.z * sbs;
-        const int rows[3] = {ym, y, yp};
-        int acc[4] = {0, 0, 0, 0};
+    const uint8_t* s = src + blockIdx.z * sbs;
+    // horizontal differences (right neighbour - left neighbour) of the quad in source row yy
+    int hd[XS_ROWS + 2][4];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t* row = (const uint32_t*)(s + (size_t)rows[k] * sp);
-            const uint32_t a = xq > 0 ? row[xq - 1] : 0u, b = row[xq], c = (xq + 1 < nq) ? row[xq + 1] : 0u;
-            const int wgt = (k == 1) ? 2 : 1;
-            // pixel j of the quad: right neighbour - left neighbour
-            const int p_m1 = (int)(a >> 24), p0 = (int)(b & 0xFF), p1 = (int)((b >> 8) & 0xFF), p2 = (int)((b >> 16) & 0xFF), p3 = (int)(b >> 24),
-                      p4 = (int)(c & 0xFF);
-            acc[0] += wgt * (p1 - p_m1);
-            acc[1] += wgt * (p2 - p0);
-            acc[2] += wgt * (p3 - p1);
-            acc[3] += wgt * (p4 - p2);
-        }
-        out = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int x = x0 + j;
-            int v = (x == 0 || x >= w - 1) ? cap : clampi(acc[j], -cap, cap) + cap;
-            out |= (uint32_t)v << (8 * j);
-        }
+    for (int k = 0; k < XS_ROWS + 2; k++) {
+        int yy = yb - 1 + k;
+        yy = yy < 0 ? (h > 1 ? 1 : 0) : (yy > h - 1 ? (h > 1 ? 2 * (h - 1) - yy : 0) : yy);   // reflect-101
+        yy = yy < 0 ? 0 : yy;                                                                 // rows past the image (not written)
+        const uint32_t* row = (const uint32_t*)(s + (size_t)yy * sp);
+        const uint32_t a = xq > 0 ? row[xq - 1] : 0u, b = row[xq], c = (xq + 1 < nq) ? row[xq + 1] : 0u;
+        const int p_m1 = (int)(a >> 24), p0 = (int)(b & 0xFF), p1 = (int)((b >> 8) & 0xFF), p2 = (int)((b >> 16) & 0xFF), p3 = (int)(b >> 24),
+                  p4 = (int)(c & 0xFF);
+        hd[k][0] = p1 - p_m1;
+        hd[k][1] = p2 - p0;
+        hd[k][2] = p3 - p1;
+        hd[k][3] = p4 - p2;
     }
-    uint8_t* d = dst + blockIdx.z * dbs + (size_t)y * dp + x0;
-    if (x0 + 3 < w) *(uint32_t*)d = out;
-    else
-        for (int j = 0; x0 + j < w; j++) d[j] = (uint8_t)(out >> (8 * j));
+#pragma unroll
+    for (int r = 0; r < XS_ROWS; r++) {
+        const int y = yb + r;
+        if (y >= h) break;
+        uint32_t out = 0;
+        if ((h & 1) && y == h - 1) {
+            out = (uint32_t)cap * 0x01010101u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const int acc = hd[r][j] + 2 * hd[r + 1][j] + hd[r + 2][j];
+                const int v = (x == 0 || x >= w - 1) ? cap : clampi(acc, -cap, cap) + cap;
+                out |= (uint32_t)v << (8 * j);
+            }
+        }
+        uint8_t* d = dst + blockIdx.z * dbs + (size_t)y * dp + x0;
+        if (x0 + 3 < w) *(uint32_t*)d = out;
+        else
+            for (int j = 0; x0 + j < w; j++) d[j] = (uint8_t)(out >> (8 * j));
+    }
 }
 
 // NORMALIZED_RESPONSE: ((4c + l + r + u + d) * scale_g - boxsum * scale_s) >> 10, replicate borders.
@@ -330,7 +397,10 @@ int gipk_remap_u8_interp(const uint8_t* src, size_t src_pitch, int sw, int sh, u
     const int nearest = interpolation == GIP_INTER_NEAREST;
     GIPK_ARGCHECK(src && dst && map1 && map2 && w > 0 && h > 0 && sw > 0 && sh > 0 && batch > 0 && (cn == 1 || cn == 3));
     GIPK_ARGCHECK(((uintptr_t)map1 & 3) == 0 && ((uintptr_t)map2 & 1) == 0);
-    if (cn == 1)
+    if (cn == 1 && h >= 2 * RM_ROWS)
+        hipLaunchKernelGGL(k_remap_r4, dim3(gip_div_up(w, 64), gip_div_up(gip_div_up(h, RM_ROWS), 4), batch), dim3(64, 4), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst,
+                           dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
+    else if (cn == 1)
         hipLaunchKernelGGL(k_remap<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
     else
         hipLaunchKernelGGL(k_remap<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
@@ -346,7 +416,7 @@ int gipk_prefilter(const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t ds
         const bool aligned = ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0) && src_pitch % 4 == 0 && dst_pitch % 4 == 0 && sbs % 4 == 0 && dbs % 4 == 0 &&
                              src_pitch >= (size_t)((w + 3) & ~3);
         if (aligned)
-            hipLaunchKernelGGL(k_prefilter_xsobel_v4, dim3(gip_div_up(gip_div_up(w, 4), 64), gip_div_up(h, 4), batch), dim3(64, 4), 0, (hipStream_t)stream, src, src_pitch, dst,
+            hipLaunchKernelGGL(k_prefilter_xsobel_v4, dim3(gip_div_up(gip_div_up(w, 4), 64), gip_div_up(gip_div_up(h, XS_ROWS), 4), batch), dim3(64, 4), 0, (hipStream_t)stream, src, src_pitch, dst,
                                dst_pitch, w, h, prefilter_cap, sbs, dbs);
         else
             hipLaunchKernelGGL(k_prefilter_xsobel, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, prefilter_cap, sbs, dbs);

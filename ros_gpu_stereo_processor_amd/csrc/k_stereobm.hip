@@ -500,18 +500,42 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
 
     // border columns matter only to validateDisparity (they are blanked afterwards)
     const bool need_border = p->disp12_max_diff >= 0;
-    bool c4_done = false;
-    if (cend > cbeg) {
-        // preferred: column-sum matcher (k_stereobm_c4.hip) when an instantiation exists for (ndisp, block)
-        a.cbeg = cbeg; a.cend = cend;
+    auto launch_border = [&](hipStream_t bst, bool border_only) -> int {
+        const int S = g.ndisp / 16;
+        if (S > 256) return GIP_ERR_UNSUPPORTED;
+        int TC = 256 / S; if (TC < 1) TC = 1; if (TC > 64) TC = 64;
+        int widest = a.nleft > a.nright ? a.nleft : a.nright;
+        while (TC > 1 && TC / 2 >= widest) TC /= 2;
+        a.TC = TC;
+        int ntiles = gip_div_up(a.nleft, TC) + gip_div_up(a.nright, TC);
+        int nch = pick_chunks(ntiles);
+        if (border_only) {
+            // border-only launch: tiny blocks whose per-row global loads are latency bound -- use short row chunks so that
+            // many small workgroups overlap (the extra 2r warm-up rows are cheap next to the idle time they remove)
+            int short_rows = 2 * r + 8;
+            nch = gip_div_up(nrows, short_rows);
+        }
+        a.rows_per_chunk = gip_div_up(nrows, nch);
+        nch = gip_div_up(nrows, a.rows_per_chunk);
+        size_t sh = smem_bytes(2 * r + 1, TC + 2 * r, TC + 2 * r + g.ndisp + 8, TC, g.ndisp, S);
+        if (sh > 160 * 1024) return GIP_ERR_UNSUPPORTED;
+        if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_bm_generic, dim3(ntiles, nch, batch), dim3(TC * S), sh, bst, a);
+        GIP_LAUNCH_CHECK();
+        return GIP_OK;
+    };
+
+    // preferred: column-sum matcher (k_stereobm_c4.hip).  It implements the clamped-column rule itself, so it covers every
+    // output column [0, width1) and no border launch is needed
+    a.cbeg = 0; a.cend = g.width1;
+    if (gip_bm_c4_can(a)) {
+        bool c4_done = false;
         rc = gip_bm_c4_launch(a, batch, st, &c4_done);
         if (rc != GIP_OK) return rc;
+        return c4_done ? GIP_OK : GIP_ERR_UNSUPPORTED;
     }
-    if (c4_done) {
-        a.nleft = need_border ? (r < g.width1 ? r : g.width1) : 0;
-        a.nright = need_border ? r : 0;
-    } else if (fast_ok) {
-        a.cbeg = cbeg; a.cend = cend;
+    a.cbeg = cbeg; a.cend = cend;
+    if (fast_ok) {
         int ntiles = gip_div_up(cend - cbeg, 64);
         int nch = pick_chunks(ntiles);
         a.rows_per_chunk = gip_div_up(nrows, nch);
@@ -526,27 +550,8 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
         a.nleft = g.width1; a.nright = 0;
     }
     if (a.nleft + a.nright > 0) {
-        const int S = g.ndisp / 16;
-        if (S > 256) return GIP_ERR_UNSUPPORTED;
-        int TC = 256 / S; if (TC < 1) TC = 1; if (TC > 64) TC = 64;
-        int widest = a.nleft > a.nright ? a.nleft : a.nright;
-        while (TC > 1 && TC / 2 >= widest) TC /= 2;
-        a.TC = TC;
-        int ntiles = gip_div_up(a.nleft, TC) + gip_div_up(a.nright, TC);
-        int nch = pick_chunks(ntiles);
-        if (c4_done || fast_ok) {
-            // border-only launch: tiny blocks whose per-row global loads are latency bound -- use short row chunks so that
-            // many small workgroups overlap (the extra 2r warm-up rows are cheap next to the idle time they remove)
-            int short_rows = 2 * r + 8;
-            nch = gip_div_up(nrows, short_rows);
-        }
-        a.rows_per_chunk = gip_div_up(nrows, nch);
-        nch = gip_div_up(nrows, a.rows_per_chunk);
-        size_t sh = smem_bytes(2 * r + 1, TC + 2 * r, TC + 2 * r + g.ndisp + 8, TC, g.ndisp, S);
-        if (sh > 160 * 1024) return GIP_ERR_UNSUPPORTED;
-        if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(k_bm_generic, dim3(ntiles, nch, batch), dim3(TC * S), sh, st, a);
-        GIP_LAUNCH_CHECK();
+        rc = launch_border(st, fast_ok);
+        if (rc != GIP_OK) return rc;
     }
     return GIP_OK;
 }

@@ -131,9 +131,32 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
         u32 v = __builtin_amdgcn_alignbyte(hi, lo, sh);
         return (v & 0x7F7F7F7Fu) + 0x01010101u;   // +1 bias (valid pixels are <= 2*cap <= 126)
     };
+    // left image, byte-granular edge replication (clamped-column rule: left column = clamp(lofs + cc, 0, w - 1)); only the
+    // lanes whose quad straddles an image edge take the slow path
+    auto fetch_l = [&](int yy) -> u32 {
+        const int col = lcol0 + 4 * lane;
+        if (col >= 0 && col + 3 <= a.w - 1) return fetch(Lb, yy, ldw, lsh);
+        const uint8_t* row = Lb + (size_t)yy * a.pitch;
+        u32 v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v |= (u32)row[clampi(col + j, 0, a.w - 1)] << (8 * j);
+        return (v & 0x7F7F7F7Fu) + 0x01010101u;
+    };
+    // right image, clamped-column rule: window column cc reads right column rofs + clamp(cc, -rofs, w - ndisp - rofs) + d.
+    // Every column of a lane's quad that is clamped lands on the same clamp column, and a partly clamped quad contains its
+    // clamp column, so one window lane per lane (tw) and a byte position per column (psh = 8 * position) express the rule.
+    int tw;
+    u32 psh[4];
+    {
+        const int rlo = -a.rofs, rhi = a.w - a.ndisp - a.rofs;
+        const int off0 = clampi(c0 + 4 * t, rlo, rhi) - c0;
+        tw = off0 >> 2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) psh[q] = 8u * (u32)((clampi(c0 + 4 * t + q, rlo, rhi) - c0) & 3);
+    }
     u32 pf_l = 0, pf_r[NLD];
     auto prefetch = [&](int yy) {
-        if (lane < 16) pf_l = fetch(Lb, yy, ldw, lsh);
+        if (lane < 16) pf_l = fetch_l(yy);
 #pragma unroll
         for (int i = 0; i < NLD; i++)
             if (lane + 64 * i < RWD) pf_r[i] = fetch(Rb, yy, rdw + 64 * i, rsh);
@@ -162,14 +185,15 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     auto add_row = [&](int yy) {
         const u32* slot = ring + (yy % NRING) * SLOTD;
         const u32 lw = slot[t];
-        const u32* rw = slot + 16 + t + NG * s;
+        const u32* rw = slot + 16 + tw + NG * s;
         u32 rd[NG + 1];
 #pragma unroll
         for (int i = 0; i <= NG; i++) rd[i] = rw[i];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u32 ref = lw & (0xFFu << (8 * q));
-            TV[q] = __builtin_amdgcn_sad_u8(ref, ft1 << (8 * q), TV[q]);
+            const u32 lb = (lw >> (8 * q)) & 0xFFu;
+            const u32 ref = lb << psh[q];
+            TV[q] = __builtin_amdgcn_sad_u8(lb, ft1, TV[q]);
 #pragma unroll
             for (int g = 0; g < NG; g++) V[q][g] = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, V[q][g]);
         }
@@ -177,14 +201,15 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     auto sub_row = [&](int yy) {
         const u32* slot = ring + (yy % NRING) * SLOTD;
         const u32 lw = slot[t];
-        const u32* rw = slot + 16 + t + NG * s;
+        const u32* rw = slot + 16 + tw + NG * s;
         u32 rd[NG + 1];
 #pragma unroll
         for (int i = 0; i <= NG; i++) rd[i] = rw[i];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u32 ref = lw & (0xFFu << (8 * q));
-            TV[q] -= __builtin_amdgcn_sad_u8(ref, ft1 << (8 * q), 0u);
+            const u32 lb = (lw >> (8 * q)) & 0xFFu;
+            const u32 ref = lb << psh[q];
+            TV[q] -= __builtin_amdgcn_sad_u8(lb, ft1, 0u);
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 const u64 tq = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, 0ull);
@@ -403,12 +428,25 @@ int dispatch_r(const BmArgs& a, int batch, hipStream_t st, bool* handled)
 
 }  // namespace
 
+bool gip_bm_c4_can(const BmArgs& a)
+{
+    // aligned dword staging needs 4-byte aligned rows
+    if ((a.pitch & 3) || ((uintptr_t)a.L & 3) || ((uintptr_t)a.R & 3) || (a.img_bs & 3)) return false;
+    if (a.cend <= a.cbeg) return false;
+    switch (a.ndisp) {
+    case 16: case 32: case 48: case 64: case 96: case 128: case 192: case 256: break;
+    default: return false;
+    }
+    switch (a.wsz2) {
+    case 2: case 3: case 4: case 5: case 7: case 10: return true;
+    default: return false;
+    }
+}
+
 int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled)
 {
     *handled = false;
-    // aligned dword staging needs 4-byte aligned rows
-    if ((a.pitch & 3) || ((uintptr_t)a.L & 3) || ((uintptr_t)a.R & 3) || (a.img_bs & 3)) return GIP_OK;
-    if (a.cend <= a.cbeg) return GIP_OK;
+    if (!gip_bm_c4_can(a)) return GIP_OK;
     switch (a.ndisp) {
     case 16: return dispatch_r<1>(a, batch, st, handled);
     case 32: return dispatch_r<2>(a, batch, st, handled);
