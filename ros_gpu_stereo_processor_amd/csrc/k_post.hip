@@ -74,6 +74,81 @@ __global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const int32_t* cost,
         if (x < roi_x || x >= roi_x + roi_w || x < wr0 || x >= wr1) dptr[x] = (int16_t)INVALID;
 }
 
+// Same, for rows of at most 256 * NI pixels: every thread keeps its NI pixels in registers across the three phases, so the
+// disparity row is read once and only the pixels that change are written back.
+template <int NI>
+__global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpitch, const int32_t* cost, size_t cpitch, int w, int h, int mindisp,
+                                                        int ndisp, int disp12, int roi_x, int roi_y, int roi_w, int roi_h, int wr0, int wr1, size_t dbs,
+                                                        size_t cbs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    u64* keys = (u64*)smem_raw;
+    const int y = blockIdx.x, t = threadIdx.x;
+    int16_t* dptr = (int16_t*)((uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
+    const int INVALID = (mindisp - 1) * 16;
+    if (y < roi_y || y >= roi_y + roi_h) {
+        for (int x = t; x < w; x += TPB) dptr[x] = (int16_t)INVALID;
+        return;
+    }
+    int d[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int x = t + TPB * i;
+        d[i] = x < w ? (int)dptr[x] : INVALID;
+    }
+    bool kill[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) kill[i] = false;
+    if (disp12 >= 0) {
+        const int32_t* cptr = (const int32_t*)((const uint8_t*)cost + blockIdx.z * cbs) + (size_t)y * cpitch;
+        const int minD = mindisp, maxD = mindisp + ndisp;
+        const int minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (minD < 0 ? minD : 0);
+        const int maxdiff = disp12 * 16;
+        u32 c[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int x = t + TPB * i;
+            c[i] = (x >= minX1 && x < maxX1 && d[i] != INVALID) ? (u32)cptr[x] : 0u;
+        }
+        for (int x = t; x < w; x += TPB) keys[x] = ~0ull;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int x = t + TPB * i;
+            if (x < minX1 || x >= maxX1 || d[i] == INVALID) continue;
+            const int x2 = x - ((d[i] + 8) >> 4);
+            if (x2 < 0 || x2 >= w) continue;
+            atomicMin(&keys[x2], ((u64)c[i] << 32) | ((u64)(u32)x << 16) | (u64)(unsigned short)d[i]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int x = t + TPB * i;
+            if (x < minX1 || x >= maxX1 || d[i] == INVALID) continue;
+            const int x0 = x - (d[i] >> 4), x1 = x - ((d[i] + 15) >> 4);
+            bool bad0 = false, bad1 = false;
+            if (x0 >= 0 && x0 < w) {
+                const u64 k = keys[x0];
+                if (k != ~0ull) { const int df = (int)(short)(unsigned short)(k & 0xFFFFu) - d[i]; bad0 = (df < 0 ? -df : df) > maxdiff; }
+            }
+            if (x1 >= 0 && x1 < w) {
+                const u64 k = keys[x1];
+                if (k != ~0ull) { const int df = (int)(short)(unsigned short)(k & 0xFFFFu) - d[i]; bad1 = (df < 0 ? -df : df) > maxdiff; }
+            }
+            kill[i] = bad0 && bad1;
+        }
+    }
+    // L/R failures, everything outside the valid ROI columns (after the L/R check, as OpenCV does) and the columns the
+    // matcher never writes ([wr0, wr1) = [lofs, lofs + width1) is its output range)
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int x = t + TPB * i;
+        if (x >= w) continue;
+        const bool blank = kill[i] || x < roi_x || x >= roi_x + roi_w || x < wr0 || x >= wr1;
+        if (blank && d[i] != INVALID) dptr[x] = (int16_t)INVALID;
+    }
+}
+
 __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, float* __restrict__ dst, size_t fpitch, int w, int h, float alpha,
                               float beta, size_t dbs, size_t fbs)
 {
@@ -494,9 +569,14 @@ int gipk_bm_finalize(int16_t* disp, size_t disp_pitch, const int32_t* cost, size
     if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     int rx = g.roi_x, ry = g.roi_y, rw = g.roi_w, rh = g.roi_h;
     if (g.degenerate) { rx = ry = rw = rh = 0; }
-    hipLaunchKernelGGL(k_bm_finalize, dim3(h, 1, batch), dim3(TPB), sh, (hipStream_t)stream, disp, disp_pitch / 2, cost, cost ? cost_pitch / 4 : 0, w, h,
-                       p->min_disparity, p->num_disparities, g.degenerate ? -1 : p->disp12_max_diff, rx, ry, rw, rh, g.lofs, g.lofs + g.width1, disp_bstride,
-                       cost_bstride);
+#define GIP_FINALIZE_ARGS disp, disp_pitch / 2, cost, cost ? cost_pitch / 4 : 0, w, h, p->min_disparity, p->num_disparities, g.degenerate ? -1 : p->disp12_max_diff, rx, ry, \
+                          rw, rh, g.lofs, g.lofs + g.width1, disp_bstride, cost_bstride
+    const dim3 grid(h, 1, batch);
+    if (w <= 2 * TPB) hipLaunchKernelGGL(k_bm_finalize_r<2>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    else if (w <= 5 * TPB) hipLaunchKernelGGL(k_bm_finalize_r<5>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    else if (w <= 8 * TPB) hipLaunchKernelGGL(k_bm_finalize_r<8>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    else hipLaunchKernelGGL(k_bm_finalize, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+#undef GIP_FINALIZE_ARGS
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
