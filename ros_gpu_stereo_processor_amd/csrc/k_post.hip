@@ -281,14 +281,24 @@ __global__ void __launch_bounds__(64) k_spk_scan(const int16_t* __restrict__ dis
     const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= me
     const unsigned long long lt = le >> 1;                                           // lanes <  me
     int n_run = 0, n_join = 0, carry_start = 0;
+    // the five values of a chunk are loaded one iteration ahead: the loop is a chain of ballots, and without the prefetch
+    // every iteration would wait for its own round trip to memory
+    int nv = new_val, nvl = new_val, nvr = new_val, nb = new_val, nbl = new_val;
+    auto load = [&](int c0) {
+        const int x = c0 + lane;
+        const bool in = x < w;
+        nv = in ? d0[x] : new_val;
+        nvl = (in && x > 0) ? d0[x - 1] : new_val;
+        nvr = (x + 1 < w) ? d0[x + 1] : new_val;
+        nb = (in && has_next) ? d1[x] : new_val;
+        nbl = (in && has_next && x > 0) ? d1[x - 1] : new_val;
+    };
+    load(0);
     for (int c0 = 0; c0 < w; c0 += 64) {
         const int x = c0 + lane;
         const bool in = x < w;
-        const int v = in ? d0[x] : new_val;
-        const int vl = (in && x > 0) ? d0[x - 1] : new_val;
-        const int vr = (x + 1 < w) ? d0[x + 1] : new_val;
-        const int b = (in && has_next) ? d1[x] : new_val;
-        const int bl = (in && has_next && x > 0) ? d1[x - 1] : new_val;
+        const int v = nv, vl = nvl, vr = nvr, b = nb, bl = nbl;
+        if (c0 + 64 < w) load(c0 + 64);
         const bool valid = v != new_val;
         const bool cl = spk_conn(vl, v, new_val, max_diff);   // joined to the left neighbour
         const unsigned long long smask = __ballot(valid && !cl);
@@ -312,77 +322,85 @@ __global__ void __launch_bounds__(64) k_spk_scan(const int16_t* __restrict__ dis
     }
 }
 
+// last row of a strip whose exclusive prefix offset is <= i  (off[0..R], off[R] = total)
+__device__ __forceinline__ int spk_row_of(const int* off, int R, int i)
+{
+    int lo = 0, hi = R - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(SPK_TPB) k_spk_strip(SpkScratch S, int w, int h, int nstrips)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     int* lab = (int*)smem_raw;              // SPK_CAP
     int* lsize = lab + SPK_CAP;             // SPK_CAP
-    __shared__ int off[SPK_STRIP + 1];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ int off[SPK_STRIP + 1];      // runs:  exclusive prefix over the strip's rows
+    __shared__ int joff[SPK_STRIP + 1];     // joins between two rows of the strip: same
+    const int t = threadIdx.x;
     const int y0 = blockIdx.x * SPK_STRIP;
     const int R = min(SPK_STRIP, h - y0);
     const size_t ibase = blockIdx.z * (size_t)w * h;
     const int* nrun = S.nrun + blockIdx.z * (size_t)h + y0;
     const int* njoin = S.njoin + blockIdx.z * (size_t)h + y0;
-    if (t == 0) {
-        int acc = 0;
-        for (int i = 0; i < R; i++) { off[i] = acc; acc += nrun[i]; }
-        for (int i = R; i <= SPK_STRIP; i++) off[i] = acc;
+    if (t <= SPK_STRIP) {
+        off[t] = t < R ? nrun[t] : 0;
+        joff[t] = t + 1 < R ? njoin[t] : 0;
     }
     __syncthreads();
-    const int T = off[R];
+    if (t == 0) {
+        int acc = 0, jacc = 0;
+        for (int i = 0; i <= SPK_STRIP; i++) {
+            const int n = off[i], j = joff[i];
+            off[i] = acc; joff[i] = jacc;
+            acc += n; jacc += j;
+        }
+    }
+    __syncthreads();
+    const int T = off[R], J = joff[R];
+    // every phase below runs over the flattened (row, item) space so that its global loads are all in flight at once
     if (T > SPK_CAP) {
         // too many runs for the LDS level: every run is its own strip-local root and all joins go to k_spk_cross
         if (t == 0) S.global_strip[blockIdx.z * (size_t)nstrips + blockIdx.x] = 1;
-        for (int yl = wave; yl < R; yl += SPK_TPB / 64)
-            for (int k = lane; k < nrun[yl]; k += 64) {
-                const size_t node = ibase + (size_t)(y0 + yl) * w + k;
-                S.parent[node] = (y0 + yl) * w + k;
-                S.csize[node] = (int)(S.runlist[node] >> 16);
-            }
+        for (int i = t; i < T; i += SPK_TPB) {
+            const int yl = spk_row_of(off, R, i), k = i - off[yl];
+            const size_t node = ibase + (size_t)(y0 + yl) * w + k;
+            S.parent[node] = (y0 + yl) * w + k;
+            S.csize[node] = (int)(S.runlist[node] >> 16);
+        }
         return;
     }
     if (t == 0) S.global_strip[blockIdx.z * (size_t)nstrips + blockIdx.x] = 0;
     for (int i = t; i < T; i += SPK_TPB) { lab[i] = i; lsize[i] = 0; }
     __syncthreads();
     // joins inside the strip
-    for (int yl = wave; yl + 1 < R; yl += SPK_TPB / 64) {
+    for (int j = t; j < J; j += SPK_TPB) {
+        const int yl = spk_row_of(joff, R, j);
         const size_t rb = ibase + (size_t)(y0 + yl) * w;
-        const int n = njoin[yl];
-        for (int k = lane; k < n; k += 64) {
-            const u32 item = S.joinlist[rb + k];
-            const int x = (int)(item >> 16);
-            lds_union(lab, off[yl] + (int)(item & 0xFFFFu), off[yl + 1] + (int)S.ord16[rb + w + x]);
-        }
+        const u32 item = S.joinlist[rb + (j - joff[yl])];
+        const int x = (int)(item >> 16);
+        lds_union(lab, off[yl] + (int)(item & 0xFFFFu), off[yl + 1] + (int)S.ord16[rb + w + x]);
     }
     __syncthreads();
     // sizes at the local roots; flatten
-    for (int yl = wave; yl < R; yl += SPK_TPB / 64) {
-        const size_t rb = ibase + (size_t)(y0 + yl) * w;
-        const int n = nrun[yl];
-        for (int k = lane; k < n; k += 64) {
-            const int i = off[yl] + k;
-            const int r = lds_find(lab, i);
-            atomicAdd(&lsize[r], (int)(S.runlist[rb + k] >> 16));
-            if (r != i) __hip_atomic_store(&lab[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // roots do not move any more
-        }
+    for (int i = t; i < T; i += SPK_TPB) {
+        const int yl = spk_row_of(off, R, i);
+        const int len = (int)(S.runlist[ibase + (size_t)(y0 + yl) * w + (i - off[yl])] >> 16);
+        const int r = lds_find(lab, i);
+        atomicAdd(&lsize[r], len);
+        if (r != i) __hip_atomic_store(&lab[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // roots do not move any more
     }
     __syncthreads();
-    for (int yl = wave; yl < R; yl += SPK_TPB / 64) {
-        const size_t rb = ibase + (size_t)(y0 + yl) * w;
-        const int n = nrun[yl];
-        for (int k = lane; k < n; k += 64) {
-            const int i = off[yl] + k;
-            const int r = lab[i];
-            // local index -> (row, ordinal): the last row whose offset is <= r
-            int lo = 0, hi = R - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (off[mid] <= r) lo = mid; else hi = mid - 1;
-            }
-            S.parent[rb + k] = (y0 + lo) * w + (r - off[lo]);
-            S.csize[rb + k] = (r == i) ? lsize[i] : 0;
-        }
+    for (int i = t; i < T; i += SPK_TPB) {
+        const int yl = spk_row_of(off, R, i);
+        const size_t node = ibase + (size_t)(y0 + yl) * w + (i - off[yl]);
+        const int r = lab[i];
+        const int yr = spk_row_of(off, R, r);        // local index -> (row, ordinal)
+        S.parent[node] = (y0 + yr) * w + (r - off[yr]);
+        S.csize[node] = (r == i) ? lsize[i] : 0;
     }
 }
 
@@ -611,7 +629,7 @@ int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new
     S.global_strip = S.njoin + (size_t)h * batch;    // nstrips * batch <= h * batch entries
     S.ord16 = (unsigned short*)(S.global_strip + (size_t)h * batch);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
+hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     hipLaunchKernelGGL(k_spk_strip, dim3(nstrips, 1, batch), dim3(SPK_TPB), (size_t)SPK_CAP * 8, st, S, w, h, nstrips);
     if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(64), 0, st, S, w, h, nstrips);
     hipLaunchKernelGGL(k_spk_sizes, dim3(h, 1, batch), dim3(64), 0, st, S, w, h);
