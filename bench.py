@@ -23,6 +23,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 W, H, NDISP, BLOCK = 1242, 375, 128, 9
+ENCODING = "mono8"
+# BASELINE.json configs[1] (the one `metric` is quoted on, default) and configs[2] (north_star's second size; --workload hd1080)
+WORKLOADS = {
+    "kitti": dict(W=1242, H=375, NDISP=128, BLOCK=9, ENCODING="mono8", batch=64, kernel="k_bm_c4<8,4>", slots_per_pair=7.4,
+                  name="KITTI-size 1242x375 mono8, ndisp=128 block=9, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
+                       "->speckle(800,5)->f32 disparity+PointCloud2"),
+    "hd1080": dict(W=1920, H=1080, NDISP=256, BLOCK=21, ENCODING="bayer_rggb8", batch=8, kernel="k_bm_c4<16,10>", slots_per_pair=None,
+                   name="1920x1080 bayer_rggb8, ndisp=256 block=21, full chain debayer(gray L/R + colour L)->rectify->StereoBM(XSOBEL,tex10,uniq15,"
+                        "L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
+}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -41,6 +51,8 @@ def make_inputs(batch, seed0, nseeds=4):
     ls, rs = [], []
     for i in range(nseeds):
         l, r, _, _ = synth.raw_pair(W, H, NDISP, seed=seed0 + i, calib=calib)
+        if ENCODING != "mono8":
+            l, r = synth.bayer_mosaic(synth.colorize(l, 1), ENCODING), synth.bayer_mosaic(synth.colorize(r, 2), ENCODING)
         ls.append(l)
         rs.append(r)
     idx = np.arange(batch) % nseeds
@@ -49,8 +61,12 @@ def make_inputs(batch, seed0, nseeds=4):
 
 def cpu_chain(O, lr, rr, calib, maps, po):
     """The same chain on the host cores with the oracle (the restatement of the reference's CPU path)."""
-    rl, rrect = O.remap(lr, *maps[0]), O.remap(rr, *maps[1])
-    bgr = O.gray_to_bgr(rl)
+    if ENCODING == "mono8":
+        rl, rrect = O.remap(lr, *maps[0]), O.remap(rr, *maps[1])
+        bgr = O.gray_to_bgr(rl)
+    else:
+        rl, rrect = O.remap(O.bayer_to_gray(lr, ENCODING), *maps[0]), O.remap(O.bayer_to_gray(rr, ENCODING), *maps[1])
+        bgr = O.remap(O.bayer_to_bgr(lr, ENCODING), *maps[0])
     d16 = O.stereobm(rl, rrect, po)
     d16 = O.filter_speckles(d16, -16, SPECKLE_SIZE, int(SPECKLE_DIFF * 16))
     d32 = O.disparity_to_f32(d16, calib["left"]["P"][2], calib["right"]["P"][2])
@@ -69,8 +85,9 @@ def cpu_baseline(lraw, rraw, calib, budget_s=12.0, max_pairs=64):
         n += 1
     dt = time.perf_counter() - t0
     return dict(value=round(n / dt, 3), unit="stereo pairs/s", cores=O.num_threads(), kind="port",
-                sample="%d pairs of the same 1242x375 ndisp=128 block=9 chain (remap L/R, StereoBM+L/R check, speckle, reproject, PointCloud2 pack) "
-                       "in %.1f s with the C oracle (OpenMP over row stripes); OpenCV itself is not installable here" % (n, dt))
+                sample="%d pairs of the same %dx%d ndisp=%d block=%d chain (%sremap L/R, StereoBM+L/R check, speckle, reproject, PointCloud2 pack) "
+                       "in %.1f s with the C oracle (OpenMP over row stripes); OpenCV itself is not installable here"
+                       % (n, W, H, NDISP, BLOCK, "" if ENCODING == "mono8" else "debayer, ", dt))
 
 
 def single_pair_latency(lraw, rraw, calib, params, device, iters=30):
@@ -85,16 +102,16 @@ def single_pair_latency(lraw, rraw, calib, params, device, iters=30):
     proc.setMaxSpeckleDiff(SPECKLE_DIFF)
     mask = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
     for _ in range(3):
-        proc.processPair(lraw, rraw, "mono8", mask)
+        proc.processPair(lraw, rraw, ENCODING, mask)
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter()
-        proc.processPair(lraw, rraw, "mono8", mask)
+        proc.processPair(lraw, rraw, ENCODING, mask)
         ts.append(1e3 * (time.perf_counter() - t0))
     proc.close()
     ts.sort()
     return {"single_pair_ms_p50": round(ts[len(ts) // 2], 4), "single_pair_ms_p99": round(ts[min(len(ts) - 1, int(0.99 * len(ts)))], 4),
-            "what": "gip_process_pair (imageCb schedule: upload L/R, mono, rectify L/R + colour L, StereoBM, speckle, reproject) for one 1242x375 pair, host wall time incl. sync"}
+            "what": "gip_process_pair (imageCb schedule: upload L/R, mono, rectify L/R + colour L, StereoBM, speckle, reproject) for one %dx%d pair, host wall time incl. sync" % (W, H)}
 
 
 def main():
@@ -102,10 +119,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti", help="kitti = BASELINE configs[1] (the metric's config); hd1080 = configs[2]")
+    ap.add_argument("--batch", type=int, default=0, help="stereo pairs per step per GPU (default: 64 for kitti, 8 for hd1080)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     args = ap.parse_args()
+    global W, H, NDISP, BLOCK, ENCODING
+    wl = WORKLOADS[args.workload]
+    W, H, NDISP, BLOCK, ENCODING = wl["W"], wl["H"], wl["NDISP"], wl["BLOCK"], wl["ENCODING"]
+    if args.batch <= 0:
+        args.batch = wl["batch"]
 
     import torch
     import torch.distributed as dist
@@ -132,7 +155,7 @@ def main():
     calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
     params = capi.BMParams(**bm_kwargs())
     outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
-    pipe = BatchPipeline(W, H, calib, params, B, "mono8", outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True)
+    pipe = BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True)
     pipe.install_maps(maps)
 
     left = torch.from_numpy(lraw).to(dev)
@@ -173,7 +196,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("batch") == B and tj.get("workload") == "1242x375_nd128_b9":
+                if tj.get("batch") == B and tj.get("workload") == "1242x375_nd128_b9" and args.workload == "kitti":
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -182,17 +205,17 @@ def main():
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * args.steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "KITTI-size 1242x375 mono8, ndisp=128 block=9, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
-                                   "->speckle(800,5)->f32 disparity+PointCloud2", "pairs_per_step_per_gpu": B, "parallelism": "frame-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_bm_c4<8,4>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "config": {"workload": wl["name"], "pairs_per_step_per_gpu": B, "parallelism": "frame-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_ms": round(bm_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4),
                          # the search is integer-VALU bound, not HBM bound: (pixel, disparity) pairs per second
                          # against the measured 4.2-cycle VOP3 issue rate (tools/ubench_valu.hip: 39.3 T lane-slots/s) at the
                          # kernel's ~7.4 issue slots per pair (instruction count of k_bm_c4<8,4>)
                          "valu_model": {"px_disp_pairs_per_s": round(W * H * NDISP * B / (bm_ms * 1e-3), 1) if bm_ms > 0 else 0.0,
-                                        "slots_per_pair": 7.4, "peak_lane_slots_per_s": 39.3e12,
-                                        "frac": round(W * H * NDISP * B / (bm_ms * 1e-3) * 7.4 / 39.3e12, 4) if bm_ms > 0 else 0.0}},
+                                        "slots_per_pair": wl["slots_per_pair"], "peak_lane_slots_per_s": 39.3e12,
+                                        "frac": round(W * H * NDISP * B / (bm_ms * 1e-3) * wl["slots_per_pair"] / 39.3e12, 4)
+                                        if bm_ms > 0 and wl["slots_per_pair"] else None}},
         }
         if world == 1 and not args.no_latency:
             out["latency"] = single_pair_latency(lraw[0], rraw[0], calib, params, local_rank)

@@ -92,22 +92,33 @@ struct C4Smem {
     int slotb, rwb, cspb;
 };
 
-template <int NG, int R>
-__global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
+// NW = wavefronts per workgroup.  NW = 1 is the layout described above.  With NW > 1 the waves of a workgroup work on the SAME
+// 64 columns and split the disparity range further (slice s = 4 * wave + lane / 16 of NS = 4 * NW slices): they share the row
+// ring and the cost slice, so the LDS per wave -- what limits the number of resident waves -- drops by NW, and so do the
+// vertical-sum registers per lane.  The price: real barriers, the winner keys / uniqueness counts of the waves are merged
+// through LDS, the texture sums are computed by every wave, and a wave finalises only 64 / NW pixels per row.
+template <int NG, int R, int NW>
+__global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 {
     constexpr int K = (R + 3) / 4;
     constexpr int NRING = 2 * R + 1;
-    constexpr int NDISP = 16 * NG;
-    constexpr int RWD = 17 + 4 * NG;            // right-row dwords needed per ring slot
+    constexpr int NS = 4 * NW;                  // disparity slices
+    constexpr int NT = 64 * NW;                 // threads
+    constexpr int NDISP = 4 * NG * NS;
+    constexpr int RWD = 17 + NS * NG;           // right-row dwords needed per ring slot
     constexpr int RWDP = (RWD + 3) & ~3;        // padded to 16 bytes
     constexpr int SLOTD = 16 + RWDP;            // dwords per ring slot
     constexpr int CSPB = 2 * NDISP + 16;        // bytes per column of the cost slice
-    constexpr int NLD = (RWD + 63) / 64;        // right-row dwords each lane stages per row (1 or 2)
+    constexpr int NLD = (RWD + NT - 1) / NT;    // right-row dwords each thread stages per row
+    constexpr int QPW = 4 / NW;                 // pixel columns q finalised per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     u32* ring = (u32*)smem_raw;
     uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
+    u32* xbest = (u32*)(cs + (size_t)64 * CSPB);   // [NW][16][4] winner keys of each wave   (NW > 1 only)
+    u32* xcnt = xbest + NW * 64;                    // [NW][16][4] uniqueness counts of each wave
 
-    const int lane = threadIdx.x, t = lane & 15, s = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int lane = tid & 63, t = lane & 15, sl = lane >> 4, s = 4 * wave + sl;
     const int c0 = a.cbeg - 4 * K + blockIdx.x * (64 - 8 * K);   // relative column of lane t=0, q=0
     const int ya = a.row0 + blockIdx.y * a.rows_per_chunk;
     const int yb = min(ya + a.rows_per_chunk, a.row1);
@@ -123,8 +134,8 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     const int rcol0 = a.rofs + c0;   // absolute column of R ring byte 0
     const int ndw = (int)(a.pitch >> 2);
     const int lsh = lcol0 & 3, rsh = rcol0 & 3;
-    const int ldw = (lcol0 >> 2) + lane;  // (arithmetic shift: floor for negative columns)
-    const int rdw = (rcol0 >> 2) + lane;
+    const int ldw = (lcol0 >> 2) + tid;  // (arithmetic shift: floor for negative columns)
+    const int rdw = (rcol0 >> 2) + tid;
     auto fetch = [&](const uint8_t* base, int yy, int dw, int sh) -> u32 {
         const u32* row = (const u32*)(base + (size_t)yy * a.pitch);
         u32 lo = row[clampi(dw, 0, ndw - 1)], hi = row[clampi(dw + 1, 0, ndw - 1)];
@@ -134,7 +145,7 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     // left image, byte-granular edge replication (clamped-column rule: left column = clamp(lofs + cc, 0, w - 1)); only the
     // lanes whose quad straddles an image edge take the slow path
     auto fetch_l = [&](int yy) -> u32 {
-        const int col = lcol0 + 4 * lane;
+        const int col = lcol0 + 4 * tid;
         if (col >= 0 && col + 3 <= a.w - 1) return fetch(Lb, yy, ldw, lsh);
         const uint8_t* row = Lb + (size_t)yy * a.pitch;
         u32 v = 0;
@@ -156,17 +167,17 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     }
     u32 pf_l = 0, pf_r[NLD];
     auto prefetch = [&](int yy) {
-        if (lane < 16) pf_l = fetch_l(yy);
+        if (tid < 16) pf_l = fetch_l(yy);
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (lane + 64 * i < RWD) pf_r[i] = fetch(Rb, yy, rdw + 64 * i, rsh);
+            if (tid + NT * i < RWD) pf_r[i] = fetch(Rb, yy, rdw + NT * i, rsh);
     };
     auto commit = [&](int yy) {
         u32* slot = ring + (yy % NRING) * SLOTD;
-        if (lane < 16) slot[lane] = pf_l;
+        if (tid < 16) slot[tid] = pf_l;
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (lane + 64 * i < RWD) slot[16 + lane + 64 * i] = pf_r[i];
+            if (tid + NT * i < RWD) slot[16 + tid + NT * i] = pf_r[i];
     };
 
     // ---- state
@@ -232,20 +243,18 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     for (int yy = ya - R; yy < ya + R; yy++) add_row(yy);
     prefetch(ya + R);
 
-    const int my_col = 4 * t + s;                 // the tile column this lane finalises
+    // the pixel this lane finalises: column 4t + qf.  One wave: qf = lane / 16.  NW waves: wave w takes q in [w*QPW, (w+1)*QPW),
+    // its lanes with lane / 16 >= QPW have no pixel.
+    const bool fin = sl < QPW;
+    const int qf = (wave * QPW + sl) & 3;
+    const int my_col = 4 * t + qf;
     const int c_out = c0 + my_col;
-    const bool writer = (t >= K) && (t <= 15 - K) && (c_out >= a.cbeg) && (c_out < a.cend);
-#if 1
+    const bool writer = fin && (t >= K) && (t <= 15 - K) && (c_out >= a.cbeg) && (c_out < a.cend);
     // cost slice rows ordered [q][t] (row = 16q + t): the stores of consecutive lanes are CSPB = 4 (mod 32) dwords apart
-    // (bank-conflict free); lane (s,t) finalises column 4t+s, whose row is 16s + t = its own lane index
+    // (bank-conflict free)
     constexpr int QSTRIDE = 16 * CSPB;
     uint8_t* csrow_w = cs + (size_t)t * CSPB + (size_t)(4 * NG * s) * 2;
-    const uint8_t* csrow_r = cs + (size_t)lane * CSPB;
-#else
-    constexpr int QSTRIDE = CSPB;
-    uint8_t* csrow_w = cs + (size_t)(4 * t) * CSPB + (size_t)(4 * NG * s) * 2;   // where this lane parks (column 4t+q, its groups)
-    const uint8_t* csrow_r = cs + (size_t)my_col * CSPB;
-#endif
+    const uint8_t* csrow_r = cs + (size_t)(16 * qf + t) * CSPB;
 
     for (int y = ya; y < yb; y++) {
         __syncthreads();          // single wave: orders the LDS traffic of the previous iteration before the slot is reused
@@ -293,7 +302,17 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
             best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 16));
             best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 32));
         }
-        __syncthreads();          // cost slice complete (single wave)
+        if constexpr (NW > 1) {
+            if (sl == 0) *(uint4*)(xbest + (wave * 16 + t) * 4) = make_uint4(best[0], best[1], best[2], best[3]);
+        }
+        __syncthreads();          // cost slice (and the waves' keys) complete
+        if constexpr (NW > 1) {
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) {
+                const uint4 o = *(const uint4*)(xbest + (w2 * 16 + t) * 4);
+                best[0] = umin(best[0], o.x); best[1] = umin(best[1], o.y); best[2] = umin(best[2], o.z); best[3] = umin(best[3], o.w);
+            }
+        }
 
         // uniqueness: groups whose minimum is <= the per-column threshold, summed over the quarters
         u32 cnt[4] = {0, 0, 0, 0};
@@ -307,11 +326,21 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
                 cnt[q] += (u32)__shfl_xor((int)cnt[q], 16);
                 cnt[q] += (u32)__shfl_xor((int)cnt[q], 32);
             }
+            if constexpr (NW > 1) {
+                if (sl == 0) *(uint4*)(xcnt + (wave * 16 + t) * 4) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+                __syncthreads();          // a.uniq is uniform: every wave takes this branch
+                cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; w2++) {
+                    const uint4 o = *(const uint4*)(xcnt + (w2 * 16 + t) * 4);
+                    cnt[0] += o.x; cnt[1] += o.y; cnt[2] += o.z; cnt[3] += o.w;
+                }
+            }
         }
-        // ---- finalise pixel (column 4t+s) in this lane
-        const u32 key = s == 0 ? best[0] : s == 1 ? best[1] : s == 2 ? best[2] : best[3];
-        const int tsum = (int)(s == 0 ? tsum_q[0] : s == 1 ? tsum_q[1] : s == 2 ? tsum_q[2] : tsum_q[3]);
-        const int ngle = (int)(s == 0 ? cnt[0] : s == 1 ? cnt[1] : s == 2 ? cnt[2] : cnt[3]);
+        // ---- finalise pixel (column 4t+qf) in this lane
+        const u32 key = qf == 0 ? best[0] : qf == 1 ? best[1] : qf == 2 ? best[2] : best[3];
+        const int tsum = (int)(qf == 0 ? tsum_q[0] : qf == 1 ? tsum_q[1] : qf == 2 ? tsum_q[2] : tsum_q[3]);
+        const int ngle = (int)(qf == 0 ? cnt[0] : qf == 1 ? cnt[1] : qf == 2 ? cnt[2] : cnt[3]);
         const int minsad = (int)(key >> 8), gstar = (int)(key & 0xFFu);
         const unsigned short* csw = (const unsigned short*)csrow_r;
         int d_out = a.filtered;
@@ -329,7 +358,7 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
 #pragma unroll
                 for (int dg = -1; dg <= 1; dg++) {
                     const int gg = gstar + dg;
-                    if (gg < 0 || gg >= 4 * NG) continue;
+                    if (gg < 0 || gg >= NS * NG) continue;
                     const uint2 v = *(const uint2*)(csrow_r + gg * 8);
                     const int cc[4] = {(int)(v.x & 0xFFFF), (int)(v.x >> 16), (int)(v.y & 0xFFFF), (int)(v.y >> 16)};
                     bool any_le = false;
@@ -362,19 +391,20 @@ __global__ void __launch_bounds__(64) k_bm_c4(BmArgs a)
     }
 }
 
-template <int NG, int R>
+template <int NG, int R, int NW>
 int launch_c4(const BmArgs& a, int batch, hipStream_t st)
 {
     constexpr int K = (R + 3) / 4;
-    constexpr int RWD = 17 + 4 * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
-    const size_t sh = (size_t)(2 * R + 1) * SLOTD * 4 + (size_t)64 * (2 * 16 * NG + 16);
+    constexpr int NS = 4 * NW;
+    constexpr int RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
+    const size_t sh = (size_t)(2 * R + 1) * SLOTD * 4 + (size_t)64 * (2 * 4 * NG * NS + 16) + (size_t)2 * NW * 64 * 4;
     const int ncols = a.cend - a.cbeg;
     const int ntiles = (ncols + (64 - 8 * K) - 1) / (64 - 8 * K);
     const int nrows = a.row1 - a.row0;
-    // Row chunks.  One workgroup = one wave; a CU holds floor(160 KiB / LDS per wave) of them (at most 32).  Pick the
-    // chunk count that minimises  rounds x (rows per chunk + warm-up cost): whole "rounds" of resident waves matter because
-    // a partially filled last round idles most of the chip, and every chunk re-reads 2R warm-up rows (each worth about
-    // 0.4 of a full row: SAD only, no winner-take-all).
+    // Row chunks.  A CU holds min(32 / NW, floor(160 KiB / LDS per workgroup)) workgroups.  Pick the chunk count that
+    // minimises  rounds x (rows per chunk + warm-up cost): whole "rounds" of resident workgroups matter because a partially
+    // filled last round idles most of the chip, and every chunk re-reads 2R warm-up rows (each worth about 0.4 of a full row:
+    // SAD only, no winner-take-all).
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0, v = 0;
@@ -382,7 +412,7 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st)
         else n_cu = 256;
     }
     int per_cu = (int)((160 * 1024) / (sh ? sh : 1));
-    if (per_cu > 32) per_cu = 32;
+    if (per_cu > 32 / NW) per_cu = 32 / NW;
     if (per_cu < 1) per_cu = 1;
 #ifdef C4_FIXED_CHUNKS
     int nch = C4_FIXED_CHUNKS;
@@ -403,25 +433,25 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st)
     BmArgs b = a;
     b.rows_per_chunk = (nrows + nch - 1) / nch;
     nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;
-    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     if (g_bm_ev0) GIP_HIP_CHECK(hipEventRecord(g_bm_ev0, st));
-    hipLaunchKernelGGL((k_bm_c4<NG, R>), dim3(ntiles, nch, batch), dim3(64), sh, st, b);
+    hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), dim3(ntiles, nch, batch), dim3(64 * NW), sh, st, b);
     GIP_LAUNCH_CHECK();
     if (g_bm_ev1) GIP_HIP_CHECK(hipEventRecord(g_bm_ev1, st));
     return GIP_OK;
 }
 
-template <int NG>
+template <int NG, int NW>
 int dispatch_r(const BmArgs& a, int batch, hipStream_t st, bool* handled)
 {
     *handled = true;
     switch (a.wsz2) {
-    case 2: return launch_c4<NG, 2>(a, batch, st);
-    case 3: return launch_c4<NG, 3>(a, batch, st);
-    case 4: return launch_c4<NG, 4>(a, batch, st);
-    case 5: return launch_c4<NG, 5>(a, batch, st);
-    case 7: return launch_c4<NG, 7>(a, batch, st);
-    case 10: return launch_c4<NG, 10>(a, batch, st);
+    case 2: return launch_c4<NG, 2, NW>(a, batch, st);
+    case 3: return launch_c4<NG, 3, NW>(a, batch, st);
+    case 4: return launch_c4<NG, 4, NW>(a, batch, st);
+    case 5: return launch_c4<NG, 5, NW>(a, batch, st);
+    case 7: return launch_c4<NG, 7, NW>(a, batch, st);
+    case 10: return launch_c4<NG, 10, NW>(a, batch, st);
     default: *handled = false; return GIP_OK;
     }
 }
@@ -430,6 +460,9 @@ int dispatch_r(const BmArgs& a, int batch, hipStream_t st, bool* handled)
 
 bool gip_bm_c4_can(const BmArgs& a)
 {
+#ifdef NO_C4
+    return false;
+#endif
     // aligned dword staging needs 4-byte aligned rows
     if ((a.pitch & 3) || ((uintptr_t)a.L & 3) || ((uintptr_t)a.R & 3) || (a.img_bs & 3)) return false;
     if (a.cend <= a.cbeg) return false;
@@ -447,15 +480,27 @@ int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled)
 {
     *handled = false;
     if (!gip_bm_c4_can(a)) return GIP_OK;
+    // (groups per slice, waves): ndisp = 16 * NG * NW.  The wave counts are measured choices (tools/bm_ab.py): 2 or 4
+    // waves are 12 % slower at ndisp 128 (any batch size), 2 waves are 38 % faster at ndisp 192 (4 waves: 28 %), 4 waves 25 %
+    // faster at ndisp 256 (2 waves: 12 %)
+#ifndef C4_NW_128
+#define C4_NW_128 1
+#endif
+#ifndef C4_NW_192
+#define C4_NW_192 2
+#endif
+#ifndef C4_NW_256
+#define C4_NW_256 4
+#endif
     switch (a.ndisp) {
-    case 16: return dispatch_r<1>(a, batch, st, handled);
-    case 32: return dispatch_r<2>(a, batch, st, handled);
-    case 48: return dispatch_r<3>(a, batch, st, handled);
-    case 64: return dispatch_r<4>(a, batch, st, handled);
-    case 96: return dispatch_r<6>(a, batch, st, handled);
-    case 128: return dispatch_r<8>(a, batch, st, handled);
-    case 192: return dispatch_r<12>(a, batch, st, handled);
-    case 256: return dispatch_r<16>(a, batch, st, handled);
+    case 16: return dispatch_r<1, 1>(a, batch, st, handled);
+    case 32: return dispatch_r<2, 1>(a, batch, st, handled);
+    case 48: return dispatch_r<3, 1>(a, batch, st, handled);
+    case 64: return dispatch_r<4, 1>(a, batch, st, handled);
+    case 96: return dispatch_r<6, 1>(a, batch, st, handled);
+    case 128: return dispatch_r<8 / C4_NW_128, C4_NW_128>(a, batch, st, handled);
+    case 192: return dispatch_r<12 / C4_NW_192, C4_NW_192>(a, batch, st, handled);
+    case 256: return dispatch_r<16 / C4_NW_256, C4_NW_256>(a, batch, st, handled);
     default: return GIP_OK;
     }
 }

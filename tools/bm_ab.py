@@ -6,7 +6,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ros_gpu_stereo_processor_amd import capi, synth
 
-W, H, B = 1242, 375, 64
+W, H, B = int(os.environ.get('AB_W', 1242)), int(os.environ.get('AB_H', 375)), int(os.environ.get('AB_B', 64))
+ND, BLK = int(os.environ.get('AB_ND', 128)), int(os.environ.get('AB_BLOCK', 9))
 paths = [a for a in sys.argv[1:] if a.endswith(".so")]
 libs = [C.CDLL(os.path.abspath(p)) for p in paths]
 for L in libs:
@@ -14,10 +15,10 @@ for L in libs:
     L.gipk_stereobm_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(capi.BMParams)]
     L.gipk_stereobm.argtypes = capi.PROTOTYPES["gipk_stereobm"][1]
 dev = torch.device("cuda:0")
-pairs = [synth.rectified_pair(W, H, 128, seed=300 + i)[:2] for i in range(4)]
+pairs = [synth.rectified_pair(W, H, ND, seed=300 + i)[:2] for i in range(4)]
 l = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).to(dev)
 r = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).to(dev)
-p = capi.BMParams(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=9, min_disparity=0, num_disparities=128, texture_threshold=10,
+p = capi.BMParams(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=BLK, min_disparity=0, num_disparities=ND, texture_threshold=10,
                   uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
 outs, scr = [], []
 for L in libs:
