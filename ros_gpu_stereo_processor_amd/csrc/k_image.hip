@@ -58,12 +58,12 @@ __device__ __forceinline__ int bayer_site(int pattern, int y, int x)
 
 // Border rule of the CPU demosaic: column 0 / w-1 copy columns 1 / w-2, then row 0 / h-1 copy rows 1 / h-2.
 // Equivalent gather form: output (y,x) = interior value at (clamp(y,1,h-2), clamp(x,1,w-2)).
+// BY_ROWS pixels of one column per thread (independent pixels: their loads are in flight together; see k_remap_r4).
+constexpr int BY_ROWS = 4;
 template <bool GRAY>
-__global__ void k_bayer(const uint8_t* __restrict__ src, size_t sp, uint8_t* __restrict__ dst, size_t dp, int w, int h, int pattern,
-                        size_t sbs, size_t dbs)
+__device__ __forceinline__ void bayer_pixel(const uint8_t* __restrict__ src, size_t sp, uint8_t* __restrict__ dst, size_t dp, int w, int h, int pattern,
+                                            size_t sbs, size_t dbs, int x, int y)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
     uint8_t* d = dst + blockIdx.z * dbs + (size_t)y * dp + (GRAY ? x : 3 * x);
     if (w <= 2 || h <= 2) {
         if (GRAY) d[0] = 0; else { d[0] = 0; d[1] = 0; d[2] = 0; }
@@ -102,6 +102,17 @@ __global__ void k_bayer(const uint8_t* __restrict__ src, size_t sp, uint8_t* __r
     }
 }
 
+template <bool GRAY>
+__global__ void k_bayer(const uint8_t* __restrict__ src, size_t sp, uint8_t* __restrict__ dst, size_t dp, int w, int h, int pattern,
+                        size_t sbs, size_t dbs)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = (blockIdx.y * blockDim.y + threadIdx.y) * BY_ROWS;
+    if (x >= w) return;
+#pragma unroll
+    for (int j = 0; j < BY_ROWS; j++)
+        if (y0 + j < h) bayer_pixel<GRAY>(src, sp, dst, dp, w, h, pattern, sbs, dbs, x, y0 + j);
+}
+
 __global__ void k_mono8_to_mono16(const uint8_t* __restrict__ src, size_t sp, uint16_t* __restrict__ dst, size_t dp, int w, int h,
                                   size_t sbs, size_t dbs)
 {
@@ -127,41 +138,7 @@ __global__ void k_mono16_to_mono8(const uint16_t* __restrict__ src, size_t sp, u
 // ---------------------------------------------------------------------------------------------- remap
 // cv::remap(CV_16SC2 + CV_16UC1, INTER_LINEAR, BORDER_CONSTANT 0): weights (32-ay)(32-ax)*32..., (sum + 2^14) >> 15.
 // Gather kernel: 6 B/px of map traffic + 4 taps (L2/L1 hits for mild distortion) + CN B/px store.
-template <int CN>
-__global__ void k_remap(const uint8_t* __restrict__ src, size_t sp, int sw, int sh, uint8_t* __restrict__ dst, size_t dp, int w, int h,
-                        const int16_t* __restrict__ map1, const uint16_t* __restrict__ map2, size_t sbs, size_t dbs, int nearest)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    size_t o = (size_t)y * w + x;
-    int2 m; { const short2 t = ((const short2*)map1)[o]; m.x = t.x; m.y = t.y; }
-    int a = map2[o] & 1023, ax = a & 31, ay = a >> 5;
-    int sx = m.x, sy = m.y;
-    int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
-    bool x0 = (unsigned)sx < (unsigned)sw, x1 = (unsigned)(sx + 1) < (unsigned)sw;
-    bool y0 = (unsigned)sy < (unsigned)sh, y1 = (unsigned)(sy + 1) < (unsigned)sh;
-    const uint8_t* s = src + blockIdx.z * sbs;
-    uint8_t* d = dst + blockIdx.z * dbs + (size_t)y * dp + (size_t)x * CN;
-    if (nearest) {
-        // cv::remap INTER_NEAREST on fixed-point maps rounds the 5-bit fractions half-up (NNDeltaTab_i)
-        const int nx = sx + (ax >= 16), ny = sy + (ay >= 16);
-        const bool in = (unsigned)nx < (unsigned)sw && (unsigned)ny < (unsigned)sh;
-#pragma unroll
-        for (int k = 0; k < CN; k++) d[k] = in ? s[(size_t)ny * sp + nx * CN + k] : (uint8_t)0;
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < CN; k++) {
-        int p00 = (x0 && y0) ? s[(size_t)sy * sp + sx * CN + k] : 0;
-        int p01 = (x1 && y0) ? s[(size_t)sy * sp + (sx + 1) * CN + k] : 0;
-        int p10 = (x0 && y1) ? s[(size_t)(sy + 1) * sp + sx * CN + k] : 0;
-        int p11 = (x1 && y1) ? s[(size_t)(sy + 1) * sp + (sx + 1) * CN + k] : 0;
-        int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 16384) >> 15;
-        d[k] = (uint8_t)(v > 255 ? 255 : v);
-    }
-}
-
-// Mono, 4 pixels per thread (same column, 4 consecutive rows).  A gather kernel like this one is latency bound, not
+// 4 pixels per thread (same column, 4 consecutive rows).  A gather kernel like this one is latency bound, not
 // bandwidth bound: its time is (waves / resident wave slots) x (map load -> tap load round trip).  Four pixels per thread
 // issue 8 map loads and then 16 taps back to back, so a quarter of the waves pay the same two round trips.  The lanes of a
 // wave stay on ADJACENT columns: every load instruction still touches one or two cache lines (4 adjacent columns per lane
@@ -170,6 +147,7 @@ __global__ void k_remap(const uint8_t* __restrict__ src, size_t sp, int sw, int 
 #define RM_ROWS_N 4
 #endif
 constexpr int RM_ROWS = RM_ROWS_N;
+template <int CN>
 __global__ void k_remap_r4(const uint8_t* __restrict__ src, size_t sp, int sw, int sh, uint8_t* __restrict__ dst, size_t dp, int w, int h,
                            const int16_t* __restrict__ map1, const uint16_t* __restrict__ map2, size_t sbs, size_t dbs, int nearest)
 {
@@ -186,34 +164,43 @@ __global__ void k_remap_r4(const uint8_t* __restrict__ src, size_t sp, int sw, i
         fr[j] = map2[o] & 1023;
     }
     const uint8_t* s = src + blockIdx.z * sbs;
-    uint8_t* d = dst + blockIdx.z * dbs + (size_t)y0 * dp + x;
+    uint8_t* d = dst + blockIdx.z * dbs + (size_t)y0 * dp + (size_t)x * CN;
     if (nearest) {
 #pragma unroll
         for (int j = 0; j < RM_ROWS; j++) {
             const int nx = sx[j] + ((fr[j] & 31) >= 16), ny = sy[j] + ((fr[j] >> 5) >= 16);
             const bool in = (unsigned)nx < (unsigned)sw && (unsigned)ny < (unsigned)sh;
-            const uint8_t v = in ? s[(size_t)ny * sp + nx] : (uint8_t)0;
-            if (y0 + j < h) d[(size_t)j * dp] = v;
+#pragma unroll
+            for (int k = 0; k < CN; k++) {
+                const uint8_t v = in ? s[(size_t)ny * sp + nx * CN + k] : (uint8_t)0;
+                if (y0 + j < h) d[(size_t)j * dp + k] = v;
+            }
         }
         return;
     }
-    int p[RM_ROWS][4];
+    int p[RM_ROWS][CN][4];
 #pragma unroll
     for (int j = 0; j < RM_ROWS; j++) {
         const bool bx0 = (unsigned)sx[j] < (unsigned)sw, bx1 = (unsigned)(sx[j] + 1) < (unsigned)sw;
         const bool by0 = (unsigned)sy[j] < (unsigned)sh, by1 = (unsigned)(sy[j] + 1) < (unsigned)sh;
-        const uint8_t* q = s + (ptrdiff_t)sy[j] * (ptrdiff_t)sp + sx[j];
-        p[j][0] = (bx0 && by0) ? q[0] : 0;
-        p[j][1] = (bx1 && by0) ? q[1] : 0;
-        p[j][2] = (bx0 && by1) ? q[sp] : 0;
-        p[j][3] = (bx1 && by1) ? q[sp + 1] : 0;
+        const uint8_t* q = s + (ptrdiff_t)sy[j] * (ptrdiff_t)sp + (ptrdiff_t)sx[j] * CN;
+#pragma unroll
+        for (int k = 0; k < CN; k++) {
+            p[j][k][0] = (bx0 && by0) ? q[k] : 0;
+            p[j][k][1] = (bx1 && by0) ? q[CN + k] : 0;
+            p[j][k][2] = (bx0 && by1) ? q[sp + k] : 0;
+            p[j][k][3] = (bx1 && by1) ? q[sp + CN + k] : 0;
+        }
     }
 #pragma unroll
     for (int j = 0; j < RM_ROWS; j++) {
         const int ax = fr[j] & 31, ay = fr[j] >> 5;
         const int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
-        const int v = (p[j][0] * w00 + p[j][1] * w01 + p[j][2] * w10 + p[j][3] * w11 + 16384) >> 15;
-        if (y0 + j < h) d[(size_t)j * dp] = (uint8_t)(v > 255 ? 255 : v);
+#pragma unroll
+        for (int k = 0; k < CN; k++) {
+            const int v = (p[j][k][0] * w00 + p[j][k][1] * w01 + p[j][k][2] * w10 + p[j][k][3] * w11 + 16384) >> 15;
+            if (y0 + j < h) d[(size_t)j * dp + k] = (uint8_t)(v > 255 ? 255 : v);
+        }
     }
 }
 
@@ -352,7 +339,7 @@ int gipk_cvt_bayer_to_bgr(const uint8_t* src, size_t src_pitch, uint8_t* dst, si
                           size_t dbs, gip_stream stream)
 {
     GIPK_ARGCHECK(src && dst && w > 0 && h > 0 && batch > 0 && pattern >= 0 && pattern < 4);
-    hipLaunchKernelGGL(k_bayer<false>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, pattern, sbs, dbs);
+    hipLaunchKernelGGL(k_bayer<false>, dim3(gip_div_up(w, 64), gip_div_up(gip_div_up(h, BY_ROWS), 4), batch), dim3(64, 4), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, pattern, sbs, dbs);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
@@ -361,7 +348,7 @@ int gipk_cvt_bayer_to_gray(const uint8_t* src, size_t src_pitch, uint8_t* dst, s
                            size_t dbs, gip_stream stream)
 {
     GIPK_ARGCHECK(src && dst && w > 0 && h > 0 && batch > 0 && pattern >= 0 && pattern < 4);
-    hipLaunchKernelGGL(k_bayer<true>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, pattern, sbs, dbs);
+    hipLaunchKernelGGL(k_bayer<true>, dim3(gip_div_up(w, 64), gip_div_up(gip_div_up(h, BY_ROWS), 4), batch), dim3(64, 4), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, pattern, sbs, dbs);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
@@ -397,13 +384,11 @@ int gipk_remap_u8_interp(const uint8_t* src, size_t src_pitch, int sw, int sh, u
     const int nearest = interpolation == GIP_INTER_NEAREST;
     GIPK_ARGCHECK(src && dst && map1 && map2 && w > 0 && h > 0 && sw > 0 && sh > 0 && batch > 0 && (cn == 1 || cn == 3));
     GIPK_ARGCHECK(((uintptr_t)map1 & 3) == 0 && ((uintptr_t)map2 & 1) == 0);
-    if (cn == 1 && h >= 2 * RM_ROWS)
-        hipLaunchKernelGGL(k_remap_r4, dim3(gip_div_up(w, 64), gip_div_up(gip_div_up(h, RM_ROWS), 4), batch), dim3(64, 4), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst,
-                           dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
-    else if (cn == 1)
-        hipLaunchKernelGGL(k_remap<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
+    const dim3 g4(gip_div_up(w, 64), gip_div_up(gip_div_up(h, RM_ROWS), 4), batch), b4(64, 4);
+    if (cn == 1)
+        hipLaunchKernelGGL(k_remap_r4<1>, g4, b4, 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
     else
-        hipLaunchKernelGGL(k_remap<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
+        hipLaunchKernelGGL(k_remap_r4<3>, g4, b4, 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
