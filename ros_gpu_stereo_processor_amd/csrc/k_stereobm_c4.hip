@@ -70,18 +70,37 @@ __device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi 
 
 // Horizontal window sum for output column q of this lane from the in-lane prefix sums P[0..4] (P[0] = 0) of every lane:
 //   window = columns [4t+q-R, 4t+q+R];  lane t+d covers columns 4(t+d)..4(t+d)+3  ->  sub-columns [lo,hi]
+// Optional (-DC4_OPAQUE): an empty asm the running sum passes through, which keeps the compiler from folding two neighbour
+// terms into one v_add3_u32 (VOP3 cannot take a DPP operand); each neighbour term then becomes ONE v_add_u32_dpp instead of
+// v_mov_b32_dpp x 2 + v_add3_u32 (2 instructions per window sum instead of 3).  Measured: -0.5 % at block 9, but +8 % at
+// block 15 and +9 % at block 21 (the adds form a serial chain with DPP wait states), so it is off.
+#ifdef C4_OPAQUE
+__device__ __forceinline__ void opaque(u32& x) { asm("" : "+v"(x)); }
+#else
+__device__ __forceinline__ void opaque(u32&) {}
+#endif
+__device__ __forceinline__ void opaque(P2& x) { opaque(x.lo); opaque(x.hi); }
+
 template <int R, int Q, class T, class SHIFT>
 __device__ __forceinline__ T hsum(const T (&P)[5], SHIFT&& shift)
 {
     constexpr int K = (R + 3) / 4;
+    // own lane first (no shift), then one add per neighbour lane
+    constexpr int lo0 = (Q - R) > 0 ? (Q - R) : 0;
+    constexpr int hi0 = (Q + R) < 3 ? (Q + R) : 3;
     T acc{};
+    if constexpr (lo0 <= hi0) {
+        if constexpr (lo0 == 0) acc = P[hi0 + 1];
+        else acc = P[hi0 + 1] - P[lo0];
+    }
     static_for<0, 2 * K + 1>([&](auto iv) {
         constexpr int d = decltype(iv)::value - K;
         constexpr int lo = (Q - R - 4 * d) > 0 ? (Q - R - 4 * d) : 0;
         constexpr int hi = (Q + R - 4 * d) < 3 ? (Q + R - 4 * d) : 3;
-        if constexpr (lo <= hi) {
+        if constexpr (d != 0 && lo <= hi) {
             if constexpr (lo == 0) acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1]);
             else acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1] - P[lo]);
+            opaque(acc);
         }
     });
     return acc;
