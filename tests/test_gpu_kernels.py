@@ -117,6 +117,10 @@ BM_CASES = [
     (97, 33, 48, 13, 0, 3, 0, 0),
     (64, 64, 64, 5, 0, 10, 15, 1),       # width1 == 1
     (300, 40, 80, 31, 0, 10, 15, 1),     # largest block of the u16 path
+    (700, 40, 256, 5, 0, 10, 15, 1),     # ndisp 256 = four waves per workgroup sharing the cost slice, smallest block
+    (500, 40, 192, 9, -16, 10, 15, 1),   # ndisp 192 = two waves per workgroup, negative minDisparity (clamped right-image columns)
+    (500, 40, 192, 11, 5, 10, 0, 1),     # ... positive minDisparity, uniqueness test off (no count exchange between the waves)
+    (340, 36, 256, 15, 0, 0, 25, 0),     # ndisp 256, width1 = 85: a single tile whose clamped borders meet
 ]
 
 
