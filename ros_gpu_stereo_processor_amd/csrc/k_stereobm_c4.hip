@@ -361,45 +361,55 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
         const int tsum = (int)(qf == 0 ? tsum_q[0] : qf == 1 ? tsum_q[1] : qf == 2 ? tsum_q[2] : tsum_q[3]);
         const int ngle = (int)(qf == 0 ? cnt[0] : qf == 1 ? cnt[1] : qf == 2 ? cnt[2] : cnt[3]);
         const int minsad = (int)(key >> 8), gstar = (int)(key & 0xFFu);
-        const unsigned short* csw = (const unsigned short*)csrow_r;
         int d_out = a.filtered;
         {
-            const uint2 grp = *(const uint2*)(csrow_r + gstar * 8);
-            const int c0v = grp.x & 0xFFFF, c1v = grp.x >> 16, c2v = grp.y & 0xFFFF;
-            const int k = (c0v == minsad) ? 0 : (c1v == minsad) ? 1 : (c2v == minsad) ? 2 : 3;   // first minimum
+            // The winner's group and its two neighbours in ONE LDS round trip: 12 costs as six packed dwords D0..D5, entry
+            // 4 + k is the winner (k = first minimum inside its group), entries 3 + k / 5 + k its sub-pixel neighbours.
+            // Groups beyond either end of the range read as 0xFFFF (never <= a threshold; a real cost is < 0xFFFF).
+            constexpr int NGT = NS * NG;
+            const bool has_m = gstar > 0, has_p = gstar + 1 < NGT;
+            const uint2 gm_ = *(const uint2*)(csrow_r + (has_m ? gstar - 1 : gstar) * 8);
+            const uint2 g0_ = *(const uint2*)(csrow_r + gstar * 8);
+            const uint2 gp_ = *(const uint2*)(csrow_r + (has_p ? gstar + 1 : gstar) * 8);
+            const u32 D0 = has_m ? gm_.x : ~0u, D1 = has_m ? gm_.y : ~0u, D2 = g0_.x, D3 = g0_.y, D4 = has_p ? gp_.x : ~0u, D5 = has_p ? gp_.y : ~0u;
+            const u32 ms = (u32)minsad;
+            const u32 h1 = D1 >> 16, h2 = D2 & 0xFFFFu, h3 = D2 >> 16, h4 = D3 & 0xFFFFu, h5 = D3 >> 16, h6 = D4 & 0xFFFFu;
+            const int k = (h2 == ms) ? 0 : (h3 == ms) ? 1 : (h4 == ms) ? 2 : 3;   // first minimum
             const int mind = 4 * gstar + k;
             bool ok = tsum >= a.tex_thr;
-            if (a.uniq > 0 && ok) {
-                const int thr = minsad + (minsad * a.uniq) / 100;
-                // groups that can hold the winner's neighbours: gstar-1 .. gstar+1
-                int touch_le = 0;
-                bool viol = false;
-#pragma unroll
-                for (int dg = -1; dg <= 1; dg++) {
-                    const int gg = gstar + dg;
-                    if (gg < 0 || gg >= NS * NG) continue;
-                    const uint2 v = *(const uint2*)(csrow_r + gg * 8);
-                    const int cc[4] = {(int)(v.x & 0xFFFF), (int)(v.x >> 16), (int)(v.y & 0xFFFF), (int)(v.y >> 16)};
-                    bool any_le = false;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int d = 4 * gg + j;
-                        const bool le = cc[j] <= thr;
-                        any_le |= le;
-                        viol |= le && (d < mind - 1 || d > mind + 1);
-                    }
-                    touch_le += any_le ? 1 : 0;
-                }
+            if (a.uniq > 0) {
+                // exact part of the uniqueness test on the 12 costs, packed: "some u16 of x is <= thr"  <=>  pk_min(x, T1) != T1
+                // with T1 = thr + 1 in both halves
+                const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
+                const u32 t1 = umin(thr + 1u, 0xFFFFu), T1 = t1 | (t1 << 16);
+                const int touch_le = (pk_min_u16(pk_min_u16(D0, D1), T1) != T1) + (pk_min_u16(pk_min_u16(D2, D3), T1) != T1) +
+                                     (pk_min_u16(pk_min_u16(D4, D5), T1) != T1);
+                // blank entries 3+k .. 5+k (the winner and its neighbours): a 48-bit window sliding over (D1, D2, D3, D4)
+                const u64 wlo = 0xFFFFFFFFFFFF0000ull << (16 * k), whi = 0x0000FFFFFFFFFFFFull >> (16 * (3 - k));
+                const u32 E1 = D1 | (u32)wlo, E2 = D2 | (u32)(wlo >> 32), E3 = D3 | (u32)whi, E4 = D4 | (u32)(whi >> 32);
+                const u32 rest = pk_min_u16(pk_min_u16(pk_min_u16(D0, E1), pk_min_u16(E2, E3)), pk_min_u16(E4, D5));
+                const bool viol = pk_min_u16(rest, T1) != T1;
                 // a group that does not touch the winner lies entirely outside [mind-1, mind+1]
-                ok = !viol && (ngle <= touch_le);
+                ok = ok && !viol && (ngle <= touch_le);
             }
-            if (ok) {
-                const int ip = (mind + 1 == NDISP) ? NDISP - 2 : mind + 1;
-                const int in = (mind == 0) ? 1 : mind - 1;
-                const int p = csw[ip], n = csw[in];
-                const int den = p + n - 2 * minsad + (p > n ? p - n : n - p);
-                const int v = (NDISP - mind - 1 + a.mindisp) * 256 + (den != 0 ? (p - n) * 256 / den : 0) + 15;
-                d_out = v >> 4;
+            {
+                u32 n = k == 0 ? h1 : k == 1 ? h2 : k == 2 ? h3 : h4;
+                u32 p = k == 0 ? h3 : k == 1 ? h4 : k == 2 ? h5 : h6;
+                const u32 n0 = n;
+                if (mind == 0) n = p;                    // OpenCV: the missing neighbour is replaced by the other one
+                if (mind + 1 == NDISP) p = n0;
+                // (p - n) * 256 / den, C truncation; den = 2 * (max(p, n) - minsad) >= 2 |p - n|, so |quotient| <= 128 and
+                // |p - n| * 256 < 2^24: one float reciprocal plus a one-step correction is exact
+                const u32 ad = p > n ? p - n : n - p;
+                const u32 den = p + n - 2u * ms + ad;
+                const u32 num = ad << 8;
+                u32 q0 = (u32)((float)num * __frcp_rn((float)den));
+                const int r = (int)(num - q0 * den);
+                q0 += (r >= (int)den) ? 1u : 0u;
+                q0 -= (r < 0) ? 1u : 0u;
+                const int quot = den != 0 ? (p >= n ? (int)q0 : -(int)q0) : 0;
+                const int v = (NDISP - mind - 1 + a.mindisp) * 256 + quot + 15;
+                if (ok) d_out = v >> 4;
             }
         }
         if (writer) {

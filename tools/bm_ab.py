@@ -19,7 +19,7 @@ pairs = [synth.rectified_pair(W, H, ND, seed=300 + i)[:2] for i in range(4)]
 l = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).to(dev)
 r = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).to(dev)
 p = capi.BMParams(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=BLK, min_disparity=0, num_disparities=ND, texture_threshold=10,
-                  uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+                  uniqueness_ratio=int(os.environ.get("AB_UNIQ", 15)), disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
 outs, scr = [], []
 for L in libs:
     n = L.gipk_stereobm_scratch_bytes(W, H, B, C.byref(p))
