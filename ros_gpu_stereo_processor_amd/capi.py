@@ -182,6 +182,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libgpuimageproc_hip.so is missing (%s): run `python -m ros_gpu_stereo_processor_amd.build`; "
                                "there is no CPU fallback" % LIB_PATH)
+        # torch first: its wheel bundles a HIP runtime (torch/lib/libamdhip64.so) with the same SONAME as /opt/rocm's.  Whichever
+        # is loaded first serves the whole process; loading ours before torch left this library without a visible device on
+        # the GPU box (gip_create -> GIP_ERR_NO_DEVICE) while torch itself still saw the GPU.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
