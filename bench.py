@@ -74,8 +74,23 @@ def cpu_chain(O, lr, rr, calib, maps, po):
     return d16, O.pack_pointcloud2(xyz, bgr)
 
 
-def cpu_baseline(lraw, rraw, calib, budget_s=12.0, max_pairs=64):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_chain_timed(workload, budget_s, max_pairs, seed0=100):
+    """Times the oracle chain on the host cores; honours OMP_NUM_THREADS.  Returns (pairs, seconds, threads)."""
+    global W, H, NDISP, BLOCK, ENCODING
+    wl = WORKLOADS[workload]
+    W, H, NDISP, BLOCK, ENCODING = wl["W"], wl["H"], wl["NDISP"], wl["BLOCK"], wl["ENCODING"]
     from oracle import oracle as O
+    lraw, rraw, calib = make_inputs(2, seed0, nseeds=2)
     maps = [O.init_undistort_rectify_map(calib[s]["K"], calib[s]["D"], calib[s]["R"], calib[s]["P"], W, H) for s in ("left", "right")]
     po = O.bm_params(**bm_kwargs())
     cpu_chain(O, lraw[0], rraw[0], calib, maps, po)  # warm-up
@@ -83,11 +98,50 @@ def cpu_baseline(lraw, rraw, calib, budget_s=12.0, max_pairs=64):
     while n < max_pairs and (time.perf_counter() - t0) < budget_s:
         cpu_chain(O, lraw[n % len(lraw)], rraw[n % len(rraw)], calib, maps, po)
         n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=round(n / dt, 3), unit="stereo pairs/s", cores=O.num_threads(), kind="port",
+    return n, time.perf_counter() - t0, O.num_threads()
+
+
+def _cpu_share():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (the GPU box shows 128 logical CPUs but a
+    1-GPU job owns a 16-CPU share; 128 OpenMP threads on that share ran the chain SLOWER than one thread)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(workload, budget_s=5.0, workers=None):
+    """Whole-host throughput of the oracle chain: one single-threaded worker process per available CPU, every worker running
+    the chain on its own frames (frames are independent -- the same sharding the GPUs use), none of them touching the GPU.
+    This is how a CPU box would be used for THROUGHPUT; OpenCV's own StereoBM only splits a 1242x375 frame into 5 row stripes."""
+    import subprocess
+    workers = workers or min(_cpu_share(), 64)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-chain-only", workload, str(budget_s)]
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
+    res = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=budget_s * 6 + 60)
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            p.kill()
+    if not res:
+        return dict(value=None, unit="stereo pairs/s", cores=0, kind="port", sample="CPU baseline workers failed")
+    pairs = sum(r["pairs"] for r in res)
+    secs = max(r["seconds"] for r in res)
+    one = sum(r["pairs"] / r["seconds"] for r in res) / len(res)
+    wl = WORKLOADS[workload]
+    return dict(value=round(pairs / secs, 2), unit="stereo pairs/s", cores=len(res), kind="port",
                 sample="%d pairs of the same %dx%d ndisp=%d block=%d chain (%sremap L/R, StereoBM+L/R check, speckle, reproject, PointCloud2 pack) "
-                       "in %.1f s with the C oracle (OpenMP over row stripes); OpenCV itself is not installable here"
-                       % (n, W, H, NDISP, BLOCK, "" if ENCODING == "mono8" else "debayer, ", dt))
+                       "in %.1f s: %d single-threaded worker processes of the C oracle, one per CPU of this job's share, each on its own frames; "
+                       "OpenCV itself is not installable here"
+                       % (pairs, wl["W"], wl["H"], wl["NDISP"], wl["BLOCK"], "" if wl["ENCODING"] == "mono8" else "debayer, ", secs, len(res)),
+                cpu_model=_cpu_model(), logical_cpus_visible=os.cpu_count(), per_worker_pairs_per_s=round(one, 3))
 
 
 def single_pair_latency(lraw, rraw, calib, params, device, iters=30):
@@ -115,6 +169,10 @@ def single_pair_latency(lraw, rraw, calib, params, device, iters=30):
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-chain-only":   # child of cpu_baseline(): host cores only, no GPU, no torch
+        n, dt, threads = _cpu_chain_timed(sys.argv[2], budget_s=float(sys.argv[3]) if len(sys.argv) > 3 else 6.0, max_pairs=100000)
+        print(json.dumps({"pairs": n, "seconds": dt, "threads": threads}))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -249,7 +307,7 @@ def main():
         if world == 1 and not args.no_latency:
             out["latency"] = single_pair_latency(lraw[0], rraw[0], calib, params, local_rank)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lraw[:4], rraw[:4], calib)
+            out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     for p in pipes:
         p.close()
