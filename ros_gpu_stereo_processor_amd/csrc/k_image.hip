@@ -278,26 +278,54 @@ __global__ void k_prefilter_xsobel_v4(const uint8_t* __restrict__ src, size_t sp
 }
 
 // NORMALIZED_RESPONSE: ((4c + l + r + u + d) * scale_g - boxsum * scale_s) >> 10, replicate borders.
-// Direct box sum (winsize is 5..9 in practice; correctness for any odd size up to 255).
-__global__ void k_prefilter_norm(const uint8_t* __restrict__ src, size_t sp, uint8_t* __restrict__ dst, size_t dp, int w, int h, int winsize,
-                                 int cap, size_t sbs, size_t dbs)
+// NORMALIZED_RESPONSE with separable box sums: a workgroup owns 256 columns (+ the 2r halo columns) and walks down a chunk
+// of rows; every thread keeps the vertical sum of the 2r+1 window rows for its one or two columns in a register (one pixel
+// enters, one leaves per row), parks it in LDS (double buffered: one barrier per row) and the output pixel adds up the 2r+1
+// column sums around it.  O(winsize) LDS reads per pixel instead of the O(winsize^2) global reads of k_prefilter_norm
+// (0.75 ms -> see DESIGN.md for 64 images at winsize 9).
+constexpr int PN_TPB = 256;
+constexpr int PN_ROWS = 32;
+__global__ void __launch_bounds__(PN_TPB) k_prefilter_norm_sep(const uint8_t* __restrict__ src, size_t sp, uint8_t* __restrict__ dst, size_t dp, int w, int h,
+                                                                int winsize, int cap, size_t sbs, size_t dbs)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    const int r = winsize / 2, ncol = PN_TPB + 2 * r;          // ncol <= 510: at most two columns per thread
+    int* colsum = (int*)smem_raw;                               // [2][ncol]
+    const int t = threadIdx.x, x0 = blockIdx.x * PN_TPB;
+    const int ya = blockIdx.y * PN_ROWS, yb = min(ya + PN_ROWS, h);
     const uint8_t* s = src + blockIdx.z * sbs;
-    int wsz2 = winsize / 2;
     int scale_g = winsize * winsize / 8, scale_s = (1024 + scale_g) / (scale_g * 2);
     scale_g *= scale_s;
-    int sum = 0;
-    for (int dy = -wsz2; dy <= wsz2; dy++) {
-        const uint8_t* row = s + (size_t)clampi(y + dy, 0, h - 1) * sp;
-        for (int dx = -wsz2; dx <= wsz2; dx++) sum += row[clampi(x + dx, 0, w - 1)];
+    // my columns (clamped to the image: replicate border)
+    const int c0 = clampi(x0 - r + t, 0, w - 1), c1 = clampi(x0 - r + t + PN_TPB, 0, w - 1);
+    const bool has1 = t + PN_TPB < ncol;
+    int v0 = 0, v1 = 0;
+    for (int dy = -r; dy <= r; dy++) {
+        const uint8_t* row = s + (size_t)clampi(ya + dy, 0, h - 1) * sp;
+        v0 += row[c0];
+        if (has1) v1 += row[c1];
     }
-    const uint8_t* cur = s + (size_t)y * sp;
-    int c = cur[x], l = cur[clampi(x - 1, 0, w - 1)], r = cur[clampi(x + 1, 0, w - 1)];
-    int u = s[(size_t)clampi(y - 1, 0, h - 1) * sp + x], dn = s[(size_t)clampi(y + 1, 0, h - 1) * sp + x];
-    int val = ((c * 4 + l + r + u + dn) * scale_g - sum * scale_s) >> 10;
-    dst[blockIdx.z * dbs + (size_t)y * dp + x] = (uint8_t)(clampi(val, -cap, cap) + cap);
+    const int x = x0 + t;
+    for (int y = ya; y < yb; y++) {
+        int* cs = colsum + ((y - ya) & 1) * ncol;
+        cs[t] = v0;
+        if (has1) cs[t + PN_TPB] = v1;
+        __syncthreads();
+        if (x < w) {
+            int sum = 0;
+            for (int k = 0; k <= 2 * r; k++) sum += cs[t + k];
+            const uint8_t* cur = s + (size_t)y * sp;
+            const int c = cur[x], l = cur[clampi(x - 1, 0, w - 1)], rr = cur[clampi(x + 1, 0, w - 1)];
+            const int u = s[(size_t)clampi(y - 1, 0, h - 1) * sp + x], dn = s[(size_t)clampi(y + 1, 0, h - 1) * sp + x];
+            const int val = ((c * 4 + l + rr + u + dn) * scale_g - sum * scale_s) >> 10;
+            dst[blockIdx.z * dbs + (size_t)y * dp + x] = (uint8_t)(clampi(val, -cap, cap) + cap);
+        }
+        // slide the window one row down
+        const uint8_t* rin = s + (size_t)clampi(y + r + 1, 0, h - 1) * sp;
+        const uint8_t* rout = s + (size_t)clampi(y - r, 0, h - 1) * sp;
+        v0 += (int)rin[c0] - (int)rout[c0];
+        if (has1) v1 += (int)rin[c1] - (int)rout[c1];
+    }
 }
 
 inline dim3 grid2d(int w, int h, int batch) { return dim3(gip_div_up(w, TPB), h, batch); }
@@ -407,7 +435,8 @@ int gipk_prefilter(const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t ds
             hipLaunchKernelGGL(k_prefilter_xsobel, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, prefilter_cap, sbs, dbs);
     } else if (prefilter_type == GIP_PREFILTER_NORMALIZED_RESPONSE) {
         GIPK_ARGCHECK(prefilter_size >= 5 && prefilter_size <= 255 && (prefilter_size & 1));
-        hipLaunchKernelGGL(k_prefilter_norm, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, prefilter_size, prefilter_cap, sbs, dbs);
+        hipLaunchKernelGGL(k_prefilter_norm_sep, dim3(gip_div_up(w, PN_TPB), gip_div_up(h, PN_ROWS), batch), dim3(PN_TPB), (size_t)2 * (PN_TPB + 2 * (prefilter_size / 2)) * sizeof(int),
+                           (hipStream_t)stream, src, src_pitch, dst, dst_pitch, w, h, prefilter_size, prefilter_cap, sbs, dbs);
     } else {
         return GIP_ERR_INVALID_ARG;
     }

@@ -93,6 +93,16 @@ def test_prefilters(gpu, oracle, shape):
             assert np.array_equal(_n(K.prefilter(_t(img, gpu), capi.PREFILTER_NORMALIZED_RESPONSE, ws, 31)), oracle.prefilter_norm(img, ws, 31)), ws
 
 
+def test_prefilter_norm_wide_windows(gpu, oracle):
+    """Window sizes whose halo gives a thread two columns (winsize up to 255) and images narrower / shorter than the window."""
+    from ros_gpu_stereo_processor_amd import kernels as K, capi
+    rng = np.random.default_rng(99)
+    for shape, sizes in (((70, 300), (65, 255)), ((40, 20), (31, 77)), ((300, 530), (129,))):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for ws in sizes:
+            assert np.array_equal(_n(K.prefilter(_t(img, gpu), capi.PREFILTER_NORMALIZED_RESPONSE, ws, 31)), oracle.prefilter_norm(img, ws, 31)), (shape, ws)
+
+
 # ---------------------------------------------------------------- block matcher
 def _prefiltered_pair(oracle, w, h, ndisp, seed):
     l, r, _ = synth.rectified_pair(w, h, min(ndisp, max(16, w // 3)), seed)
