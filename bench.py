@@ -32,6 +32,9 @@ WORKLOADS = {
     "hd1080": dict(W=1920, H=1080, NDISP=256, BLOCK=21, ENCODING="bayer_rggb8", batch=8, kernel="k_bm_c4<16,10>", slots_per_pair=None,
                    name="1920x1080 bayer_rggb8, ndisp=256 block=21, full chain debayer(gray L/R + colour L)->rectify->StereoBM(XSOBEL,tex10,uniq15,"
                         "L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
+    "uhd4k": dict(W=4096, H=2160, NDISP=192, BLOCK=15, ENCODING="mono8", batch=1, kernel="k_bm_c4<6,7,2>", slots_per_pair=None,
+                  name="4096x2160 mono8, ndisp=192 block=15, ONE frame per step on one GPU (BASELINE configs[4] without the row split), full chain "
+                       "rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -177,8 +180,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti", help="kitti = BASELINE configs[1] (the metric's config); hd1080 = configs[2]")
-    ap.add_argument("--batch", type=int, default=0, help="stereo pairs per step per GPU (default: 64 for kitti, 8 for hd1080)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti", help="kitti = BASELINE configs[1] (the metric's config); hd1080 = configs[2]; uhd4k = the frame of configs[4] on one GPU")
+    ap.add_argument("--batch", type=int, default=0, help="stereo pairs per step per GPU (default: 64 for kitti, 8 for hd1080, 1 for uhd4k)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight per GPU (each on its own HIP stream with its own buffers): the pre/post "
                     "kernels of one batch overlap the matcher of the other (measured +11 %% over --depth 1)")
     ap.add_argument("--alone", action="store_true", help="also time the dominant kernel with nothing else in flight (three extra untimed steps) "
