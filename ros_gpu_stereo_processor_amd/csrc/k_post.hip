@@ -322,6 +322,66 @@ __global__ void __launch_bounds__(64) k_spk_scan(const int16_t* __restrict__ dis
     }
 }
 
+// The same scan with TWO pixels per lane (128 columns per step, dword loads and stores): sub-dword accesses cost the memory
+// pipeline as much as dwords, so this halves its work.  Needs an even width and 4-byte aligned rows; k_spk_scan is the fallback.
+__global__ void __launch_bounds__(64) k_spk_scan2(const int16_t* __restrict__ disp, size_t dpitch, SpkScratch S, int w, int h, int new_val,
+                                                   int max_diff, size_t dbs)
+{
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const int16_t* d0 = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
+    const int16_t* d1 = d0 + dpitch;
+    const bool has_next = y + 1 < h;
+    const size_t base = blockIdx.z * (size_t)w * h + (size_t)y * w;
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= me
+    const unsigned long long lt = le >> 1;                                           // lanes <  me
+    const u32 nvp = (u32)(unsigned short)new_val * 0x10001u;                         // two invalid pixels
+    auto load2 = [&](const int16_t* row, int x, bool on) -> u32 { return (on && x < w) ? *(const u32*)(row + x) : nvp; };
+    int n_run = 0, n_join = 0, carry_start = 0;
+    int pv = new_val, pb = new_val;                 // last pixel of the previous step (rows y and y+1)
+    u32 nV = load2(d0, 2 * lane, true), nB = load2(d1, 2 * lane, has_next);
+    for (int c0 = 0; c0 < w; c0 += 128) {
+        const int x0 = c0 + 2 * lane, x1 = x0 + 1;
+        const u32 V = nV, B = nB;
+        nV = load2(d0, x0 + 128, c0 + 128 < w);
+        nB = load2(d1, x0 + 128, has_next && c0 + 128 < w);
+        const int v0 = (short)(V & 0xFFFFu), v1 = (short)(V >> 16), b0 = (short)(B & 0xFFFFu), b1 = (short)(B >> 16);
+        int vl = __shfl_up(v1, 1), bl = __shfl_up(b1, 1), vr = __shfl_down(v0, 1);
+        const int nfirst = (short)((u32)__shfl((int)nV, 0) & 0xFFFFu);
+        if (lane == 0) { vl = pv; bl = pb; }
+        if (lane == 63) vr = nfirst;
+        pv = __shfl(v1, 63);
+        pb = __shfl(b1, 63);
+        const bool valid0 = v0 != new_val, valid1 = v1 != new_val;
+        const bool cl0 = spk_conn(vl, v0, new_val, max_diff), cl1 = spk_conn(v0, v1, new_val, max_diff);
+        const bool st0 = valid0 && !cl0, st1 = valid1 && !cl1;
+        const unsigned long long s0 = __ballot(st0), s1 = __ballot(st1);
+        const unsigned long long m0 = s0 & le, m1 = s1 & lt;
+        const int ord0 = n_run + __popcll(m0) + __popcll(m1) - 1, ord1 = ord0 + (st1 ? 1 : 0);
+        const int p0 = m0 ? 2 * (63 - __builtin_clzll(m0)) : -1, p1 = m1 ? 2 * (63 - __builtin_clzll(m1)) + 1 : -1;
+        const int pm = p0 > p1 ? p0 : p1;
+        const int rs0 = pm >= 0 ? c0 + pm : carry_start;
+        const int rs1 = st1 ? x1 : rs0;
+        if (x0 < w)
+            *(u32*)(S.ord16 + base + x0) = (valid0 ? (u32)ord0 : 0xFFFFu) | ((valid1 ? (u32)ord1 : 0xFFFFu) << 16);
+        if (valid0 && !cl1) S.runlist[base + ord0] = (u32)rs0 | ((u32)(x0 - rs0 + 1) << 16);           // pixel 0 closes its run
+        if (valid1 && !spk_conn(v1, vr, new_val, max_diff)) S.runlist[base + ord1] = (u32)rs1 | ((u32)(x1 - rs1 + 1) << 16);
+        // vertical joins, unless the pair one column to the left already joins the same two runs
+        const bool j0 = spk_conn(v0, b0, new_val, max_diff) && !(cl0 && spk_conn(bl, b0, new_val, max_diff) && spk_conn(vl, bl, new_val, max_diff));
+        const bool j1 = spk_conn(v1, b1, new_val, max_diff) && !(cl1 && spk_conn(b0, b1, new_val, max_diff) && spk_conn(v0, b0, new_val, max_diff));
+        const unsigned long long jm0 = __ballot(j0), jm1 = __ballot(j1);
+        const int jp = n_join + __popcll(jm0 & lt) + __popcll(jm1 & lt);
+        if (j0) S.joinlist[base + jp] = (u32)ord0 | ((u32)x0 << 16);
+        if (j1) S.joinlist[base + jp + (j0 ? 1 : 0)] = (u32)ord1 | ((u32)x1 << 16);
+        n_join += __popcll(jm0) + __popcll(jm1);
+        n_run += __popcll(s0) + __popcll(s1);
+        carry_start = __shfl(rs1, 63);
+    }
+    if (lane == 0) {
+        S.nrun[blockIdx.z * (size_t)h + y] = n_run;
+        S.njoin[blockIdx.z * (size_t)h + y] = n_join;
+    }
+}
+
 // last row of a strip whose exclusive prefix offset is <= i  (off[0..R], off[R] = total)
 __device__ __forceinline__ int spk_row_of(const int* off, int R, int i)
 {
@@ -629,7 +689,9 @@ int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new
     S.global_strip = S.njoin + (size_t)h * batch;    // nstrips * batch <= h * batch entries
     S.ord16 = (unsigned short*)(S.global_strip + (size_t)h * batch);
     hipStream_t st = (hipStream_t)stream;
-hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
+const bool pairs_ok = (w % 2 == 0) && (disp_pitch % 4 == 0) && ((uintptr_t)disp % 4 == 0) && (disp_bstride % 4 == 0) && ((uintptr_t)S.ord16 % 4 == 0);
+    if (pairs_ok) hipLaunchKernelGGL(k_spk_scan2, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
+    else hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     hipLaunchKernelGGL(k_spk_strip, dim3(nstrips, 1, batch), dim3(SPK_TPB), (size_t)SPK_CAP * 8, st, S, w, h, nstrips);
     if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(64), 0, st, S, w, h, nstrips);
     hipLaunchKernelGGL(k_spk_sizes, dim3(h, 1, batch), dim3(64), 0, st, S, w, h);
