@@ -334,6 +334,10 @@ typedef struct gip_batch_desc {
     int16_t *disparity;     /* device out: batch*h*w int16 (always written) */
     float *disparity_f32;   /* device out or NULL */
     uint8_t *pointcloud;    /* device out or NULL: batch*h*w*32 bytes */
+    gip_stream matcher_stream; /* NULL, or a stream the dominant kernel (the SAD matcher) is launched on instead of `stream`,
+                                * fenced by events on both sides.  Pipelines that keep several batches in flight pass ONE
+                                * shared stream here: the matchers then run back to back instead of time-sharing, which is what
+                                * keeps the batches from falling into lock step */
 } gip_batch_desc;
 int gip_batch_set_maps_device(gip_handle h, int width, int height, const int16_t *map1_l, const uint16_t *map2_l,
                               const int16_t *map1_r, const uint16_t *map2_r);

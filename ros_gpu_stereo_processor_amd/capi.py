@@ -80,7 +80,7 @@ class PointCloud2Msg(C.Structure):
 class BatchDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32),
                 ("left_raw", C.c_void_p), ("right_raw", C.c_void_p), ("disparity", C.c_void_p), ("disparity_f32", C.c_void_p),
-                ("pointcloud", C.c_void_p)]
+                ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p)]
 
 
 IMAGE_CB = C.CFUNCTYPE(None, C.POINTER(ImageMsg), C.c_void_p)

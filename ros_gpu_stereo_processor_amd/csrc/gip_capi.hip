@@ -35,6 +35,9 @@ const char* gip_last_hip_error_text() { return g_hip_err; }
 
 // timing hook used by gip_batch_run: gipk_bm_match records these around its dominant kernel when set
 thread_local hipEvent_t g_bm_ev0 = nullptr, g_bm_ev1 = nullptr;
+// gip_batch_desc::matcher_stream: the stream the matcher kernel goes to, and the two events that fork / join it
+thread_local hipStream_t g_bm_match_stream = nullptr;
+thread_local hipEvent_t g_bm_fork = nullptr, g_bm_join = nullptr;
 
 namespace {
 
@@ -86,6 +89,7 @@ struct DevBuf {
 struct gip_processor {
     int device = 0;
     hipStream_t l_strm = nullptr, r_strm = nullptr;
+    hipEvent_t match_fork = nullptr, match_join = nullptr;   // gip_batch_desc::matcher_stream fences
     std::unordered_map<int, Slot> slots;
     GipStereoModel model;
     gip_bm_params params{};
@@ -385,6 +389,8 @@ int gip_destroy(gip_handle h)
         if (b->p) hipFree(b->p);
     for (hipEvent_t e : h->tev)
         if (e) (void)hipEventDestroy(e);
+    if (h->match_fork) (void)hipEventDestroy(h->match_fork);
+    if (h->match_join) (void)hipEventDestroy(h->match_join);
     if (h->l_strm) hipStreamDestroy(h->l_strm);
     if (h->r_strm) hipStreamDestroy(h->r_strm);
     delete h;
@@ -1138,9 +1144,19 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     B_STEP(ensure_dev(h, h->bm_scratch, gipk_stereobm_scratch_bytes(w, hh, B, &bp)), "batch buffers");
     g_bm_ev0 = ev[0];
     g_bm_ev1 = ev[1];
+    if (d->matcher_stream && (hipStream_t)d->matcher_stream != st) {
+        if (!h->match_fork) {
+            H_HIP(h, hipEventCreateWithFlags(&h->match_fork, hipEventDisableTiming));
+            H_HIP(h, hipEventCreateWithFlags(&h->match_join, hipEventDisableTiming));
+        }
+        g_bm_match_stream = (hipStream_t)d->matcher_stream;
+        g_bm_fork = h->match_fork;
+        g_bm_join = h->match_join;
+    }
     rc = gipk_stereobm((const uint8_t*)h->b_rect[0].p, (const uint8_t*)h->b_rect[1].p, rp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, rplane,
                        npx * 2, st);
     g_bm_ev0 = g_bm_ev1 = nullptr;
+    g_bm_match_stream = nullptr;
     if (rc != GIP_OK) return propagate(h, rc, "stereobm");
     if (h->max_speckle_size > 0) {
         B_STEP(ensure_dev(h, h->spk_scratch, gipk_speckle_scratch_bytes(w, hh, B)), "batch buffers");

@@ -29,6 +29,8 @@
 #include <utility>
 
 extern thread_local hipEvent_t g_bm_ev0, g_bm_ev1;
+extern thread_local hipStream_t g_bm_match_stream;
+extern thread_local hipEvent_t g_bm_fork, g_bm_join;
 
 namespace {
 
@@ -463,10 +465,20 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st)
     b.rows_per_chunk = (nrows + nch - 1) / nch;
     nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;
     if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    if (g_bm_ev0) GIP_HIP_CHECK(hipEventRecord(g_bm_ev0, st));
-    hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), dim3(ntiles, nch, batch), dim3(64 * NW), sh, st, b);
+    hipStream_t ks = st;
+    if (g_bm_match_stream) {
+        ks = g_bm_match_stream;
+        GIP_HIP_CHECK(hipEventRecord(g_bm_fork, st));
+        GIP_HIP_CHECK(hipStreamWaitEvent(ks, g_bm_fork, 0));
+    }
+    if (g_bm_ev0) GIP_HIP_CHECK(hipEventRecord(g_bm_ev0, ks));
+    hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), dim3(ntiles, nch, batch), dim3(64 * NW), sh, ks, b);
     GIP_LAUNCH_CHECK();
-    if (g_bm_ev1) GIP_HIP_CHECK(hipEventRecord(g_bm_ev1, st));
+    if (g_bm_ev1) GIP_HIP_CHECK(hipEventRecord(g_bm_ev1, ks));
+    if (g_bm_match_stream) {
+        GIP_HIP_CHECK(hipEventRecord(g_bm_join, ks));
+        GIP_HIP_CHECK(hipStreamWaitEvent(st, g_bm_join, 0));
+    }
     return GIP_OK;
 }
 

@@ -49,8 +49,9 @@ class BatchPipeline:
         self._maps = maps  # keep alive
         capi.check(self._lib.gip_batch_set_maps_device(self.proc.handle, self.w, self.h, *[m.data_ptr() for m in maps]), self.proc.handle)
 
-    def run(self, left_raw, right_raw):
-        """left_raw/right_raw: (B,H,W) or (B,H,W,3) uint8 CUDA tensors.  Asynchronous on torch's current stream."""
+    def run(self, left_raw, right_raw, matcher_stream=None):
+        """left_raw/right_raw: (B,H,W) or (B,H,W,3) uint8 CUDA tensors.  Asynchronous on torch's current stream.
+        matcher_stream: optional torch.cuda.Stream shared by all pipelines of the process for the SAD matcher kernel."""
         assert left_raw.is_cuda and left_raw.is_contiguous() and right_raw.is_contiguous() and left_raw.shape[0] == self.batch
         d = capi.BatchDesc()
         d.width, d.height, d.batch = self.w, self.h, self.batch
@@ -60,6 +61,7 @@ class BatchPipeline:
         d.disparity = self.disparity.data_ptr()
         d.disparity_f32 = self.disparity_f32.data_ptr() if self.disparity_f32 is not None else None
         d.pointcloud = self.pointcloud.data_ptr() if self.pointcloud is not None else None
+        d.matcher_stream = matcher_stream.cuda_stream if matcher_stream is not None else None
         capi.check(self._lib.gip_batch_run(self.proc.handle, C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.proc.handle)
 
     def timing_reset(self):
