@@ -603,6 +603,51 @@ __global__ void k_disp_outputs(const int16_t* __restrict__ disp, size_t dpitch, 
     store_pc2_record(pc + blockIdx.z * obs + ((size_t)y * w + x) * 32, (float)X, (float)Y, (float)Z, c);
 }
 
+// The same for the Q of a rectified stereo pair (image_geometry::StereoCameraModel::updateQ): only Q00 Q03 Q11 Q13 Q23 Q32 Q33 are
+// non-zero.  Dropping the zero terms changes no bit (x * +0.0 and + +0.0 are exact; the launcher also checks the zeros are
+// positive zeros) but more than halves the double-precision work.  This kernel runs next to the VALU-bound matcher of another batch, so its instruction count matters.
+constexpr int OUT_ROWS = 1;   // 4 rows per thread (64x4 blocks) halved the store bandwidth: a workgroup must write long contiguous runs
+template <int CN>
+__global__ void k_disp_outputs_sq(const int16_t* __restrict__ disp, size_t dpitch, const uint8_t* __restrict__ col, size_t cpitch,
+                                  float* __restrict__ f32out, uint8_t* __restrict__ pc, int w, int h, QMat Q, float alpha, float beta, int filtered,
+                                  size_t dbs, size_t cbs, size_t fbs, size_t obs)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = (blockIdx.y * blockDim.y + threadIdx.y) * OUT_ROWS;
+    if (x >= w || y0 >= h) return;
+    const double* q = Q.q;
+    const int16_t* dp0 = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs) + (size_t)y0 * dpitch + x;
+    int d16[OUT_ROWS];
+#pragma unroll
+    for (int j = 0; j < OUT_ROWS; j++) d16[j] = (y0 + j < h) ? (int)dp0[(size_t)j * dpitch] : filtered;
+    u32 c[OUT_ROWS];
+#pragma unroll
+    for (int j = 0; j < OUT_ROWS; j++) {
+        c[j] = 0;
+        if (col && pc && y0 + j < h) {
+            const uint8_t* cp = col + blockIdx.z * cbs + (size_t)(y0 + j) * cpitch + (size_t)CN * x;
+            if (CN == 1) c[j] = (u32)cp[0] * 0x010101u;
+            else c[j] = (u32)cp[0] | ((u32)cp[1] << 8) | ((u32)cp[2] << 16);
+        }
+    }
+    const double qx = q[3] + q[0] * x;
+#pragma unroll
+    for (int j = 0; j < OUT_ROWS; j++) {
+        const int y = y0 + j;
+        if (y >= h) break;
+        float df = (float)d16[j] * alpha;
+        df = df + beta;
+        if (f32out) ((float*)((uint8_t*)f32out + blockIdx.z * fbs))[(size_t)y * w + x] = df;
+        if (!pc) continue;
+        const double d = df;
+        const double qy = q[5] * y + q[7];
+        const double iW = 1. / (q[15] + q[14] * d);
+        const double X = qx * iW, Y = qy * iW;
+        double Z = q[11] * iW;
+        if (d16[j] == filtered) Z = 10000.;
+        store_pc2_record(pc + blockIdx.z * obs + ((size_t)y * w + x) * 32, (float)X, (float)Y, (float)Z, c[j]);
+    }
+}
+
 // cv::cuda::drawColorDisp: HSV ramp (S = V = 1) of the integer disparity; invalid (< 0) -> 0
 __global__ void k_draw_color_disp(const int16_t* __restrict__ disp, size_t dpitch, uint8_t* __restrict__ bgra, size_t bpitch, int w, int h, int ndisp,
                                   size_t dbs, size_t bbs)
@@ -733,12 +778,19 @@ int gipk_disparity_outputs(const int16_t* disp, size_t disp_pitch, const uint8_t
     for (int i = 0; i < 16; i++) q.q[i] = Q[i];
     const float alpha = (float)(1.0 / 16), beta = (float)(-(cx_l - cx_r));
     const size_t npx = (size_t)w * h;
-    if (color && color_cn == 1)
-        hipLaunchKernelGGL(k_disp_outputs<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q,
-                           alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32);
-    else
-        hipLaunchKernelGGL(k_disp_outputs<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q,
-                           alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32);
+    // the Q of a rectified stereo pair: every entry outside {0, 3, 5, 7, 11, 14, 15} is +0.0
+    bool stereo_q = true;
+    for (int i : {1, 2, 4, 6, 8, 9, 10, 12, 13}) stereo_q = stereo_q && Q[i] == 0.0 && !std::signbit(Q[i]);
+#define GIP_OUT_ARGS disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q, alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32
+    const dim3 g4(gip_div_up(w, TPB), gip_div_up(h, OUT_ROWS), batch), b4(TPB, 1);
+    if (color && color_cn == 1) {
+        if (stereo_q) hipLaunchKernelGGL(k_disp_outputs_sq<1>, g4, b4, 0, (hipStream_t)stream, GIP_OUT_ARGS);
+        else hipLaunchKernelGGL(k_disp_outputs<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, GIP_OUT_ARGS);
+    } else {
+        if (stereo_q) hipLaunchKernelGGL(k_disp_outputs_sq<3>, g4, b4, 0, (hipStream_t)stream, GIP_OUT_ARGS);
+        else hipLaunchKernelGGL(k_disp_outputs<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, GIP_OUT_ARGS);
+    }
+#undef GIP_OUT_ARGS
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }

@@ -228,6 +228,26 @@ def test_speckle_filter_bit_exact(gpu, oracle):
             assert np.array_equal(got[b], oracle.filter_speckles(batch[b], -16, max_size, max_diff)), (max_size, max_diff, b)
 
 
+def test_fused_cloud_general_q_matrix(gpu, oracle, calib, kitchen):
+    """The fused disparity -> cloud kernel has a specialised form for the sparse Q of a rectified pair; a dense Q (every entry
+    non-zero) takes the general form.  Both must agree with reprojectImageTo3D + the PointCloud2 packing of the oracle."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    Pl, Pr = calib["left"]["P"], calib["right"]["P"]
+    d16 = oracle.stereobm(kitchen["left_rect"], kitchen["right_rect"], oracle.bm_params(block_size=15, num_disparities=64))[:203, :301].copy()
+    bgr = np.stack([kitchen["left_rect"][:203, :301]] * 3, -1).copy()
+    Qs = np.asarray(oracle.stereo_q(Pl, Pr), np.float64).reshape(4, 4)
+    Qd = Qs + np.array([[0, 1e-3, 2e-3, 0], [3e-3, 0, 1e-3, 0], [1e-4, 2e-4, 3e-4, 0], [1e-6, 2e-6, 0, 0]])
+    for Q in (Qs, Qd):
+        f = oracle.disparity_to_f32(d16, Pl[2], Pr[2])
+        pc_exp = oracle.pack_pointcloud2(oracle.reproject_to_3d(f, Q.reshape(-1), True), bgr)
+        pc_got = _n(K.disparity_to_pointcloud2(_t(d16, gpu), _t(bgr, gpu), Q.reshape(-1), Pl[2], Pr[2], 0))
+        fx, ex = pc_got[..., :12].copy().view(np.float32), pc_exp[..., :12].copy().view(np.float32)
+        assert np.array_equal(np.isnan(fx), np.isnan(ex))
+        fin = np.isfinite(ex)
+        assert np.allclose(fx[fin], ex[fin], rtol=2.4e-7, atol=0)
+        assert np.array_equal(pc_got[..., 12:], pc_exp[..., 12:])
+
+
 def test_speckle_filter_dense_runs_and_odd_shapes(gpu, oracle):
     """Noise maps have one run per pixel: more runs per 32-row strip than the LDS level holds, so the strip is merged by the
     global union-find instead (k_spk_strip fallback); the half-noise map mixes both kinds of strips.  Odd shapes cover widths
