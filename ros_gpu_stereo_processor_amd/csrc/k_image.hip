@@ -147,10 +147,12 @@ __global__ void k_mono16_to_mono8(const uint16_t* __restrict__ src, size_t sp, u
 #define RM_ROWS_N 4
 #endif
 constexpr int RM_ROWS = RM_ROWS_N;
-template <int CN>
+template <int CN, int IM>
 __global__ void k_remap_r4(const uint8_t* __restrict__ src, size_t sp, int sw, int sh, uint8_t* __restrict__ dst, size_t dp, int w, int h,
                            const int16_t* __restrict__ map1, const uint16_t* __restrict__ map2, size_t sbs, size_t dbs, int nearest)
 {
+    // IM images of the batch per thread: the table entry, the tap offsets, the border predicates and the blend weights of a
+    // pixel position are the same for every image of a batch, only the taps differ -- decode once, gather IM times.
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = (blockIdx.y * blockDim.y + threadIdx.y) * RM_ROWS;
     if (x >= w || y0 >= h) return;
     int sx[RM_ROWS], sy[RM_ROWS], fr[RM_ROWS];
@@ -163,35 +165,41 @@ __global__ void k_remap_r4(const uint8_t* __restrict__ src, size_t sp, int sw, i
         sy[j] = t.y;
         fr[j] = map2[o] & 1023;
     }
-    const uint8_t* s = src + blockIdx.z * sbs;
-    uint8_t* d = dst + blockIdx.z * dbs + (size_t)y0 * dp + (size_t)x * CN;
+    const uint8_t* s0 = src + (size_t)blockIdx.z * IM * sbs;
+    uint8_t* d0 = dst + (size_t)blockIdx.z * IM * dbs + (size_t)y0 * dp + (size_t)x * CN;
     if (nearest) {
 #pragma unroll
         for (int j = 0; j < RM_ROWS; j++) {
             const int nx = sx[j] + ((fr[j] & 31) >= 16), ny = sy[j] + ((fr[j] >> 5) >= 16);
             const bool in = (unsigned)nx < (unsigned)sw && (unsigned)ny < (unsigned)sh;
 #pragma unroll
-            for (int k = 0; k < CN; k++) {
-                const uint8_t v = in ? s[(size_t)ny * sp + nx * CN + k] : (uint8_t)0;
-                if (y0 + j < h) d[(size_t)j * dp + k] = v;
-            }
+            for (int im = 0; im < IM; im++)
+#pragma unroll
+                for (int k = 0; k < CN; k++) {
+                    const uint8_t v = in ? s0[im * sbs + (size_t)ny * sp + nx * CN + k] : (uint8_t)0;
+                    if (y0 + j < h) d0[im * dbs + (size_t)j * dp + k] = v;
+                }
         }
         return;
     }
     // (a branch-free variant -- taps loaded from clamped coordinates and zeroed by select -- executes 23 % MORE vector
     // instructions than these predicated loads: the compiler turns the predicates into exec-mask branches on the scalar unit)
-    int p[RM_ROWS][CN][4];
+    int p[IM][RM_ROWS][CN][4];
 #pragma unroll
     for (int j = 0; j < RM_ROWS; j++) {
         const bool bx0 = (unsigned)sx[j] < (unsigned)sw, bx1 = (unsigned)(sx[j] + 1) < (unsigned)sw;
         const bool by0 = (unsigned)sy[j] < (unsigned)sh, by1 = (unsigned)(sy[j] + 1) < (unsigned)sh;
-        const uint8_t* q = s + (ptrdiff_t)sy[j] * (ptrdiff_t)sp + (ptrdiff_t)sx[j] * CN;
+        const ptrdiff_t off = (ptrdiff_t)sy[j] * (ptrdiff_t)sp + (ptrdiff_t)sx[j] * CN;
 #pragma unroll
-        for (int k = 0; k < CN; k++) {
-            p[j][k][0] = (bx0 && by0) ? q[k] : 0;
-            p[j][k][1] = (bx1 && by0) ? q[CN + k] : 0;
-            p[j][k][2] = (bx0 && by1) ? q[sp + k] : 0;
-            p[j][k][3] = (bx1 && by1) ? q[sp + CN + k] : 0;
+        for (int im = 0; im < IM; im++) {
+            const uint8_t* q = s0 + im * sbs + off;
+#pragma unroll
+            for (int k = 0; k < CN; k++) {
+                p[im][j][k][0] = (bx0 && by0) ? q[k] : 0;
+                p[im][j][k][1] = (bx1 && by0) ? q[CN + k] : 0;
+                p[im][j][k][2] = (bx0 && by1) ? q[sp + k] : 0;
+                p[im][j][k][3] = (bx1 && by1) ? q[sp + CN + k] : 0;
+            }
         }
     }
     // cv::remap's fixed-point blend  (sum p*w + 2^14) >> 15  with w00 = (32-ay)(32-ax)*32 ... factors exactly into two 1-D blends:
@@ -201,11 +209,13 @@ __global__ void k_remap_r4(const uint8_t* __restrict__ src, size_t sp, int sw, i
     for (int j = 0; j < RM_ROWS; j++) {
         const int ax = fr[j] & 31, ay = fr[j] >> 5, bx = 32 - ax, by = 32 - ay;
 #pragma unroll
-        for (int k = 0; k < CN; k++) {
-            const int top = p[j][k][0] * bx + p[j][k][1] * ax, bot = p[j][k][2] * bx + p[j][k][3] * ax;
-            const int v = (top * by + bot * ay + 512) >> 10;
-            if (y0 + j < h) d[(size_t)j * dp + k] = (uint8_t)v;
-        }
+        for (int im = 0; im < IM; im++)
+#pragma unroll
+            for (int k = 0; k < CN; k++) {
+                const int top = p[im][j][k][0] * bx + p[im][j][k][1] * ax, bot = p[im][j][k][2] * bx + p[im][j][k][3] * ax;
+                const int v = (top * by + bot * ay + 512) >> 10;
+                if (y0 + j < h) d0[im * dbs + (size_t)j * dp + k] = (uint8_t)v;
+            }
     }
 }
 
@@ -417,11 +427,14 @@ int gipk_remap_u8_interp(const uint8_t* src, size_t src_pitch, int sw, int sh, u
     const int nearest = interpolation == GIP_INTER_NEAREST;
     GIPK_ARGCHECK(src && dst && map1 && map2 && w > 0 && h > 0 && sw > 0 && sh > 0 && batch > 0 && (cn == 1 || cn == 3));
     GIPK_ARGCHECK(((uintptr_t)map1 & 3) == 0 && ((uintptr_t)map2 & 1) == 0);
-    const dim3 g4(gip_div_up(w, 64), gip_div_up(gip_div_up(h, RM_ROWS), 4), batch), b4(64, 4);
-    if (cn == 1)
-        hipLaunchKernelGGL(k_remap_r4<1>, g4, b4, 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
+    const bool quad = cn == 1 && batch % 4 == 0;   // four images of the batch per thread (mono)
+    const dim3 g4(gip_div_up(w, 64), gip_div_up(gip_div_up(h, RM_ROWS), 4), quad ? batch / 4 : batch), b4(64, 4);
+    if (quad)
+        hipLaunchKernelGGL((k_remap_r4<1, 4>), g4, b4, 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
+    else if (cn == 1)
+        hipLaunchKernelGGL((k_remap_r4<1, 1>), g4, b4, 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
     else
-        hipLaunchKernelGGL(k_remap_r4<3>, g4, b4, 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
+        hipLaunchKernelGGL((k_remap_r4<3, 1>), g4, b4, 0, (hipStream_t)stream, src, src_pitch, sw, sh, dst, dst_pitch, w, h, map1, map2, sbs, dbs, nearest);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }

@@ -80,6 +80,22 @@ def test_remap_out_of_range_taps(gpu, oracle):
     assert np.array_equal(got, oracle.remap(src, m1, m2))
 
 
+def test_remap_batches_share_the_table_decode(gpu, oracle):
+    """Batches whose size is a multiple of four take the kernel form that decodes a table entry once for four images; other
+    sizes the one-image form.  Out-of-range taps included, both interpolation modes."""
+    from ros_gpu_stereo_processor_amd import kernels as K, capi
+    rng = np.random.default_rng(21)
+    m1 = rng.integers(-2, 50, (37, 61, 2)).astype(np.int16)
+    m2 = rng.integers(0, 1024, (37, 61)).astype(np.uint16)
+    for B in (8, 5):
+        src = rng.integers(0, 256, (B, 41, 47), dtype=np.uint8)
+        for interp, name in ((capi.INTER_LINEAR, "linear"), (capi.INTER_NEAREST, "nearest")):
+            got = _n(K.remap(_t(src, gpu), _t(m1, gpu), _t(m2.view(np.int16), gpu), interp))
+            for b in range(B):
+                exp = oracle.remap(src[b], m1, m2) if interp == capi.INTER_LINEAR else oracle.remap(src[b], m1, m2, nearest=True)
+                assert np.array_equal(got[b], exp), (B, name, b)
+
+
 # ---------------------------------------------------------------- prefilter
 @pytest.mark.parametrize("shape", [(480, 752), (33, 47), (2, 9)])
 def test_prefilters(gpu, oracle, shape):
