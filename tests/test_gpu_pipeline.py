@@ -60,6 +60,43 @@ def test_batch_pipeline_matches_oracle(gpu, oracle, encoding):
     pipe.close()
 
 
+def test_batch_pipeline_odd_size_batch_of_four(gpu, oracle):
+    """Odd width and height (scalar fallbacks of the speckle scan, unaligned plane rows) with a batch of four (the remap form that
+    shares the table decode between four images)."""
+    import torch
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+    O = oracle
+    w, h, nd, B = 333, 131, 48, 4
+    calib = synth.scaled_calibration(w, h)
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=11, min_disparity=0, num_disparities=nd, texture_threshold=10,
+              uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    raws = [synth.raw_pair(w, h, nd, seed=700 + i, calib=calib)[:2] for i in range(B)]
+    L = np.stack([r[0] for r in raws]); R = np.stack([r[1] for r in raws])
+    pipe = BatchPipeline(w, h, calib, capi.BMParams(**kw), B, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 0, 60, 2.0)
+    pipe.install_maps(pipe.host_maps_to_device())
+    pipe.run(torch.from_numpy(L).to(gpu), torch.from_numpy(R).to(gpu))
+    torch.cuda.synchronize()
+    d16 = pipe.disparity.cpu().numpy(); d32 = pipe.disparity_f32.cpu().numpy(); pc = pipe.pointcloud.cpu().numpy()
+    ml = O.init_undistort_rectify_map(calib["left"]["K"], calib["left"]["D"], calib["left"]["R"], calib["left"]["P"], w, h)
+    mr = O.init_undistort_rectify_map(calib["right"]["K"], calib["right"]["D"], calib["right"]["R"], calib["right"]["P"], w, h)
+    Q = O.stereo_q(calib["left"]["P"], calib["right"]["P"])
+    for b in range(B):
+        rl, rr = O.remap(L[b], *ml), O.remap(R[b], *mr)
+        exp = O.filter_speckles(O.stereobm(rl, rr, O.bm_params(**kw)), -16, 60, 32)
+        assert np.array_equal(d16[b], exp), b
+        e32 = O.disparity_to_f32(exp, calib["left"]["P"][2], calib["right"]["P"][2])
+        assert np.array_equal(d32[b], e32)
+        epc = O.pack_pointcloud2(O.reproject_to_3d(e32, Q, True), O.gray_to_bgr(rl))
+        gx, ex = pc[b][..., :12].copy().view(np.float32), epc[..., :12].copy().view(np.float32)
+        assert np.array_equal(np.isnan(gx), np.isnan(ex))
+        ok = ~np.isnan(ex)
+        assert np.allclose(gx[ok], ex[ok], rtol=2.4e-7, atol=0)
+        assert np.array_equal(pc[b][..., 12:], epc[..., 12:])
+        assert (exp != -16).mean() > 0.1
+    pipe.close()
+
+
 def test_pipelines_in_flight_with_shared_matcher_stream(gpu):
     """bench.py keeps three pipelines in flight (own streams, own buffers) whose matcher kernels go to ONE shared stream
     (gip_batch_desc::matcher_stream).  Every pipeline must still produce exactly what it produces alone."""
