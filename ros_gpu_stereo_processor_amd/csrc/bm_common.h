@@ -22,9 +22,17 @@ struct BmArgs {
     int filtered;
 };
 
-// k_stereobm_c4.hip: column-sum matcher for the interior columns.  Returns GIP_OK and sets *handled when a kernel
+// Host-side launch context of the dominant kernel (the SAD matcher); every field may be null.  Travels as an argument from
+// gip_batch_run down to the launcher (no global state).
+struct BmLaunchCtx {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;     // recorded around the matcher kernel, on the stream it is launched on
+    hipStream_t matcher_stream = nullptr;        // launch the matcher here instead of the caller's stream ...
+    hipEvent_t fork = nullptr, join = nullptr;   // ... fenced by these two events (required when matcher_stream is set)
+};
+
+// k_stereobm_c4.hip: column-sum matcher, every output column.  Returns GIP_OK and sets *handled when a kernel
 // instantiation exists for (ndisp, block radius); otherwise leaves *handled false and launches nothing.
-int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled);
+int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx, bool* handled);
 // true when gip_bm_c4_launch would handle these arguments (nothing is launched)
 bool gip_bm_c4_can(const BmArgs& a);
 

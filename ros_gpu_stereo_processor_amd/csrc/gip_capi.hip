@@ -23,6 +23,7 @@
 
 #include "gip_internal.h"
 #include "gip_model.h"
+#include "bm_common.h"
 
 // ------------------------------------------------------------------------------------------------ error text
 static thread_local char g_hip_err[512] = "";
@@ -32,12 +33,6 @@ void gip_note_hip_error(hipError_t e, const char* what, const char* file, int li
     std::snprintf(g_hip_err, sizeof g_hip_err, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
 }
 const char* gip_last_hip_error_text() { return g_hip_err; }
-
-// timing hook used by gip_batch_run: gipk_bm_match records these around its dominant kernel when set
-thread_local hipEvent_t g_bm_ev0 = nullptr, g_bm_ev1 = nullptr;
-// gip_batch_desc::matcher_stream: the stream the matcher kernel goes to, and the two events that fork / join it
-thread_local hipStream_t g_bm_match_stream = nullptr;
-thread_local hipEvent_t g_bm_fork = nullptr, g_bm_join = nullptr;
 
 namespace {
 
@@ -1142,21 +1137,22 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     }
     // stage 3: disparity + speckle (StereoProcessor.cpp:259-268)
     B_STEP(ensure_dev(h, h->bm_scratch, gipk_stereobm_scratch_bytes(w, hh, B, &bp)), "batch buffers");
-    g_bm_ev0 = ev[0];
-    g_bm_ev1 = ev[1];
+    // launch context of the matcher: timing events on the stream it runs on, and (gip_batch_desc::matcher_stream) a stream of
+    // its own fenced by a fork / join event pair
+    BmLaunchCtx mctx;
+    mctx.ev0 = ev[0];
+    mctx.ev1 = ev[1];
     if (d->matcher_stream && (hipStream_t)d->matcher_stream != st) {
         if (!h->match_fork) {
             H_HIP(h, hipEventCreateWithFlags(&h->match_fork, hipEventDisableTiming));
             H_HIP(h, hipEventCreateWithFlags(&h->match_join, hipEventDisableTiming));
         }
-        g_bm_match_stream = (hipStream_t)d->matcher_stream;
-        g_bm_fork = h->match_fork;
-        g_bm_join = h->match_join;
+        mctx.matcher_stream = (hipStream_t)d->matcher_stream;
+        mctx.fork = h->match_fork;
+        mctx.join = h->match_join;
     }
-    rc = gipk_stereobm((const uint8_t*)h->b_rect[0].p, (const uint8_t*)h->b_rect[1].p, rp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, rplane,
-                       npx * 2, st);
-    g_bm_ev0 = g_bm_ev1 = nullptr;
-    g_bm_match_stream = nullptr;
+    rc = gip_stereobm_impl((const uint8_t*)h->b_rect[0].p, (const uint8_t*)h->b_rect[1].p, rp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B,
+                           rplane, npx * 2, st, &mctx);
     if (rc != GIP_OK) return propagate(h, rc, "stereobm");
     if (h->max_speckle_size > 0) {
         B_STEP(ensure_dev(h, h->spk_scratch, gipk_speckle_scratch_bytes(w, hh, B)), "batch buffers");

@@ -56,6 +56,10 @@ static inline GipBmGeom gip_bm_geom(int w, int h, const gip_bm_params* p)
 }
 
 int gip_validate_bm_params(const gip_bm_params* p, int w, int h);
+struct BmLaunchCtx;   // bm_common.h
 int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride, size_t cost_bstride, gip_stream stream,
-                      bool skip_fill);
+                      bool skip_fill, const BmLaunchCtx* ctx);
+// gipk_stereobm with a launch context for the matcher (events around it, optional stream of its own)
+int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
+                      void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx);

@@ -12,6 +12,7 @@
 //   computeDisparityImage                  src/GPUStereoProcessor.cpp:323-330
 // These are HBM-bound passes (the cloud writes 32 B/px); integer results are bit-exact with the oracle.
 #include "gip_internal.h"
+#include "bm_common.h"
 
 namespace {
 
@@ -828,6 +829,14 @@ size_t gipk_stereobm_scratch_bytes(int w, int h, int batch, const gip_bm_params*
 int gipk_stereobm(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                   void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream)
 {
+    return gip_stereobm_impl(left, right, pitch, w, h, p, disp, disp_pitch, scratch, scratch_bytes, batch, img_bstride, disp_bstride, stream, nullptr);
+}
+
+}  // extern "C"
+
+int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
+                      void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx)
+{
     GIPK_ARGCHECK(left && right && disp && scratch && p && w > 0 && h > 0 && batch > 0);
     int rc = gip_validate_bm_params(p, w, h);
     if (rc != GIP_OK) return rc;
@@ -843,7 +852,7 @@ int gipk_stereobm(const uint8_t* left, const uint8_t* right, size_t pitch, int w
     rc = gipk_prefilter(right, pitch, rf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
     if (rc != GIP_OK) return rc;
     const bool lr = p->disp12_max_diff >= 0;
-    rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true);
+    rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true, ctx);
     if (rc != GIP_OK) return rc;
     rc = gipk_bm_finalize(disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, w, h, p, batch, disp_bstride, (size_t)w * h * 4, stream);
     if (rc != GIP_OK) return rc;
@@ -852,5 +861,3 @@ int gipk_stereobm(const uint8_t* left, const uint8_t* right, size_t pitch, int w
                                   gipk_speckle_scratch_bytes(w, h, batch), batch, disp_bstride, stream);
     return rc;
 }
-
-}  // extern "C"

@@ -23,9 +23,6 @@
 #include "gip_internal.h"
 #include "bm_common.h"
 
-// set by gip_batch_run (gip_capi.hip) to time the dominant kernel on its own stream
-extern thread_local hipEvent_t g_bm_ev0, g_bm_ev1;
-
 namespace {
 
 typedef unsigned long long u64;
@@ -397,31 +394,31 @@ __global__ void k_fill_i16(int16_t* disp, size_t dpitch, int w, int h, int value
 }
 
 template <int DPT, int NQ>
-int launch_fast(const BmArgs& a, int ntiles, int nchunks, int batch, hipStream_t st)
+int launch_fast(const BmArgs& a, int ntiles, int nchunks, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
     const int S = a.ndisp / DPT, r = a.wsz2;
     size_t sh = smem_bytes(2 * r + 1, 64 + 2 * r, 64 + 2 * r + a.ndisp - 1 + 8, 64, a.ndisp, S);
     if (sh > 160 * 1024) return GIP_ERR_UNSUPPORTED;
     if (sh > 64 * 1024)
         GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_fast<DPT, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    if (g_bm_ev0) GIP_HIP_CHECK(hipEventRecord(g_bm_ev0, st));
+    if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, st));
     hipLaunchKernelGGL((k_bm_fast<DPT, NQ>), dim3(ntiles, nchunks, batch), dim3(64 * S), sh, st, a);
     GIP_LAUNCH_CHECK();
-    if (g_bm_ev1) GIP_HIP_CHECK(hipEventRecord(g_bm_ev1, st));
+    if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, st));
     return GIP_OK;
 }
 
 template <int DPT>
-int dispatch_nq(int nq, const BmArgs& a, int ntiles, int nchunks, int batch, hipStream_t st)
+int dispatch_nq(int nq, const BmArgs& a, int ntiles, int nchunks, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
     switch (nq) {
-    case 2: return launch_fast<DPT, 2>(a, ntiles, nchunks, batch, st);
-    case 3: return launch_fast<DPT, 3>(a, ntiles, nchunks, batch, st);
-    case 4: return launch_fast<DPT, 4>(a, ntiles, nchunks, batch, st);
-    case 5: return launch_fast<DPT, 5>(a, ntiles, nchunks, batch, st);
-    case 6: return launch_fast<DPT, 6>(a, ntiles, nchunks, batch, st);
-    case 7: return launch_fast<DPT, 7>(a, ntiles, nchunks, batch, st);
-    case 8: return launch_fast<DPT, 8>(a, ntiles, nchunks, batch, st);
+    case 2: return launch_fast<DPT, 2>(a, ntiles, nchunks, batch, st, ctx);
+    case 3: return launch_fast<DPT, 3>(a, ntiles, nchunks, batch, st, ctx);
+    case 4: return launch_fast<DPT, 4>(a, ntiles, nchunks, batch, st, ctx);
+    case 5: return launch_fast<DPT, 5>(a, ntiles, nchunks, batch, st, ctx);
+    case 6: return launch_fast<DPT, 6>(a, ntiles, nchunks, batch, st, ctx);
+    case 7: return launch_fast<DPT, 7>(a, ntiles, nchunks, batch, st, ctx);
+    case 8: return launch_fast<DPT, 8>(a, ntiles, nchunks, batch, st, ctx);
     default: return GIP_ERR_UNSUPPORTED;
     }
 }
@@ -445,13 +442,13 @@ extern "C" int gipk_bm_match(const uint8_t* left, const uint8_t* right, size_t p
                              size_t disp_pitch, int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride,
                              size_t cost_bstride, gip_stream stream)
 {
-    return gip_bm_match_impl(left, right, pitch, w, h, p, disp, disp_pitch, cost, cost_pitch, batch, img_bstride, disp_bstride, cost_bstride, stream, false);
+    return gip_bm_match_impl(left, right, pitch, w, h, p, disp, disp_pitch, cost, cost_pitch, batch, img_bstride, disp_bstride, cost_bstride, stream, false, nullptr);
 }
 
 // skip_fill: the caller runs gipk_bm_finalize afterwards, which blanks every pixel the matcher does not write
 int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride, size_t cost_bstride, gip_stream stream,
-                      bool skip_fill)
+                      bool skip_fill, const BmLaunchCtx* ctx)
 {
     if (!left || !right || !disp || w <= 0 || h <= 0 || batch <= 0) return GIP_ERR_INVALID_ARG;
     if (disp_pitch % 2 || (cost && cost_pitch % 4)) return GIP_ERR_INVALID_ARG;
@@ -478,7 +475,12 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     a.disp = disp; a.dpitch = disp_pitch / 2; a.cost = cost; a.cpitch = cost ? cost_pitch / 4 : 0;
     a.img_bs = img_bstride; a.disp_bs = disp_bstride; a.cost_bs = cost_bstride; a.filtered = g.filtered;
     a.cbeg = a.cend = a.nleft = a.nright = 0; a.TC = 64;
-    if (wide) return gip_bm_wide_launch(a, g.roi_h, batch, st);
+    if (wide) {
+        if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+        rc = gip_bm_wide_launch(a, g.roi_h, batch, st);
+        if (rc == GIP_OK && ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+        return rc;
+    }
 
     const int r = g.wsz2, nrows = g.roi_h;
     // interior columns: the whole window is un-clamped for c in [r, width1 - r)
@@ -530,7 +532,7 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     a.cbeg = 0; a.cend = g.width1;
     if (gip_bm_c4_can(a)) {
         bool c4_done = false;
-        rc = gip_bm_c4_launch(a, batch, st, &c4_done);
+        rc = gip_bm_c4_launch(a, batch, st, ctx, &c4_done);
         if (rc != GIP_OK) return rc;
         return c4_done ? GIP_OK : GIP_ERR_UNSUPPORTED;
     }
@@ -540,9 +542,9 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
         int nch = pick_chunks(ntiles);
         a.rows_per_chunk = gip_div_up(nrows, nch);
         nch = gip_div_up(nrows, a.rows_per_chunk);
-        if (dpt == 64) rc = dispatch_nq<64>(nq, a, ntiles, nch, batch, st);
-        else if (dpt == 32) rc = dispatch_nq<32>(nq, a, ntiles, nch, batch, st);
-        else rc = dispatch_nq<16>(nq, a, ntiles, nch, batch, st);
+        if (dpt == 64) rc = dispatch_nq<64>(nq, a, ntiles, nch, batch, st, ctx);
+        else if (dpt == 32) rc = dispatch_nq<32>(nq, a, ntiles, nch, batch, st, ctx);
+        else rc = dispatch_nq<16>(nq, a, ntiles, nch, batch, st, ctx);
         if (rc != GIP_OK) return rc;
         a.nleft = need_border ? (r < g.width1 ? r : g.width1) : 0;
         a.nright = need_border ? r : 0;

@@ -1,20 +1,27 @@
-// k_stereobm_c4.hip -- the main SAD block matcher for gfx950 ("column-sum" form), interior columns.
+// k_stereobm_c4.hip -- the main SAD block matcher for gfx950 ("column-sum" form), every output column.
 //
 // Same semantics as k_stereobm.hip (cv::StereoBM, reference src/GPUStereoProcessor.cpp:312-321); different work mapping,
 // built around what the packed-byte SAD unit and the DPP cross-lane network of a CDNA4 wavefront do well:
 //
-//   * ONE WAVEFRONT = ONE WORKGROUP = one tile of 64 image columns x all disparities, marching down its row chunk.
-//     lane = s*16 + t :  t in [0,16) owns the 4 adjacent columns 4t..4t+3,  s in [0,4) owns a quarter of the disparity range
-//     (NG groups of 4 disparities).  No workgroup barrier exists on the hot path (a single wave needs none).
-//   * Per (column, 4 disparities) the lane keeps the VERTICAL running column sum  V' = sum over the 2r+1 window rows of
-//     |L - R|  as 4 packed u16 in a 64-bit register pair.  A row entering the window is added by one v_mqsad_pk_u16_u8
-//     whose reference dword holds the single left byte (the other three bytes are zero = masked; pixels are biased by +1 so a
-//     real pixel is never zero); the four columns of a lane share the SAME 8-byte right-image window -- column q just puts
-//     its byte at position q -- so all operands are plain aligned LDS dwords, no byte shuffling.  The row leaving the window
-//     is recomputed the same way and subtracted with two 32-bit subtracts (no borrow can cross the packed lanes).
-//   * The HORIZONTAL window sum is formed across lanes with DPP row shifts inside the 16-lane row that holds one disparity
-//     quarter: in-lane prefix sums P1..P4 of the 4 columns, then  H_q = sum over neighbour lanes of (P[hi+1] - P[lo]).
-//     Outputs are valid for lanes t in [K, 15-K], K = ceil(r/4); tiles advance by 64-8K columns.
+//   * ONE WAVEFRONT = one tile of 64 image columns x a slice of the disparities, marching down its row chunk.
+//     lane = s*16 + t :  t in [0,16) owns the 4 adjacent columns 4t..4t+3,  s in [0,4) owns a quarter of the wave's disparity
+//     range (NG groups of 4 disparities).
+//   * INTERIOR tiles (no clamped column) keep, per (lane, group), the PREFIX sums over the lane's four columns of the vertical
+//     running column sums:  P1 = V0, P2 = V0+V1, P3 = V0+V1+V2, T = V0+V1+V2+V3  (V = sum over the 2r+1 window rows of |L - R|),
+//     each as 4 packed u16 in a 64-bit register pair.  A row entering the window is added by four v_mqsad_pk_u16_u8 whose
+//     reference dword is the lane's left-image dword with 1, 2, 3 and 4 LIVE bytes (a zero byte is masked; pixels are biased by +1
+//     so a real pixel is never zero): column q sits at byte q and reads byte i+q of the lane's aligned 8-byte right-image window
+//     for disparity i, so one instruction forms a whole prefix sum -- no byte shuffling, no prefix adds.  The row leaving the
+//     window is recomputed the same way and subtracted with two 32-bit subtracts (no borrow can cross the packed lanes).
+//   * The HORIZONTAL window sum of column q of lane t is then
+//         H_q = sum of T over the whole lanes inside the window  -  P_ja(lane of the first column)  +  P_jb+1(lane of the last)
+//     i.e. for block 9:  H0 = A + P1(t+1),  H1 = A - P1(t-1) + P2(t+1),  H2 = A - P2(t-1) + P3(t+1),  H3 = A - P3(t-1) + T(t+1),
+//     A = T + T(t-1):  8 instructions per dword, every one a v_add_u32_dpp / v_sub_u32_dpp that fetches its neighbour-lane
+//     operand through the DPP row shift (hsum_pf below; the column-wise form took 21 per dword; a subtraction is written
+//     t = x(d) - acc; H = y(e) - t  because the DPP subtract always has the SHIFTED operand as minuend).  Outputs are valid for lanes
+//     t in [K, 15-K], K = ceil(r/4); tiles advance by 64-8K columns.
+//   * BORDER tiles (the clamped-column rule of OpenCV applies somewhere in the tile) keep the four column sums V0..V3 themselves
+//     (one live reference byte per v_mqsad, byte position = clamped column) and form the window sums column-wise.
 //   * Winner-take-all: per 4-disparity group a packed min and one 32-bit key (cost << 8 | group); quarters are merged with
 //     two xor-shuffles.  The row's cost slice is parked in LDS; lane (s,t) then finalises pixel 4t+s: exact winner inside the
 //     group, sub-pixel neighbours, texture test and the uniqueness test (count of groups <= threshold vs the groups that
@@ -28,9 +35,22 @@
 #include <type_traits>
 #include <utility>
 
-extern thread_local hipEvent_t g_bm_ev0, g_bm_ev1;
-extern thread_local hipStream_t g_bm_match_stream;
-extern thread_local hipEvent_t g_bm_fork, g_bm_join;
+// C4_ABLATE: bit mask for timing-only diagnostic builds (tools/ab_c4.sh): 1 no leaving-row subtract, 2 no window sums (costs = the
+// prefix sums themselves), 4 no cost-slice parking, 8 no quarter merges (ds_bpermute), 16 no finalisation.  Any bit set gives
+// WRONG disparities; the product build has none.
+#ifndef C4_ABLATE
+#define C4_ABLATE 0
+#endif
+// measured design switches (tools/ab_c4.sh, tools/bm_ab.py)
+#ifndef C4_PIPE     /* 1: subtract the leaving row at the top of the NEXT iteration from registers read before finalisation */
+#define C4_PIPE 0
+#endif
+#ifndef C4_B128     /* 1: park two groups per 16-byte LDS store */
+#define C4_B128 1
+#endif
+#ifndef C4_NOSYNC   /* 1: one-wave workgroups order their LDS traffic by program order only (no s_waitcnt drain) */
+#define C4_NOSYNC 1
+#endif
 
 namespace {
 
@@ -70,24 +90,13 @@ struct P2 { u32 lo, hi; };
 __device__ __forceinline__ P2 operator+(P2 a, P2 b) { return {a.lo + b.lo, a.hi + b.hi}; }
 __device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi - b.hi}; }
 
-// Horizontal window sum for output column q of this lane from the in-lane prefix sums P[0..4] (P[0] = 0) of every lane:
+// ---------------------------------------------------------------------------------------------------------------------------
+// Column-wise window sum (border tiles): output column q of this lane from the in-lane prefix sums P[0..4] (P[0] = 0):
 //   window = columns [4t+q-R, 4t+q+R];  lane t+d covers columns 4(t+d)..4(t+d)+3  ->  sub-columns [lo,hi]
-// Optional (-DC4_OPAQUE): an empty asm the running sum passes through, which keeps the compiler from folding two neighbour
-// terms into one v_add3_u32 (VOP3 cannot take a DPP operand); each neighbour term then becomes ONE v_add_u32_dpp instead of
-// v_mov_b32_dpp x 2 + v_add3_u32 (2 instructions per window sum instead of 3).  Measured: -0.5 % at block 9, but +8 % at
-// block 15 and +9 % at block 21 (the adds form a serial chain with DPP wait states), so it is off.
-#ifdef C4_OPAQUE
-__device__ __forceinline__ void opaque(u32& x) { asm("" : "+v"(x)); }
-#else
-__device__ __forceinline__ void opaque(u32&) {}
-#endif
-__device__ __forceinline__ void opaque(P2& x) { opaque(x.lo); opaque(x.hi); }
-
 template <int R, int Q, class T, class SHIFT>
 __device__ __forceinline__ T hsum(const T (&P)[5], SHIFT&& shift)
 {
     constexpr int K = (R + 3) / 4;
-    // own lane first (no shift), then one add per neighbour lane
     constexpr int lo0 = (Q - R) > 0 ? (Q - R) : 0;
     constexpr int hi0 = (Q + R) < 3 ? (Q + R) : 3;
     T acc{};
@@ -102,24 +111,147 @@ __device__ __forceinline__ T hsum(const T (&P)[5], SHIFT&& shift)
         if constexpr (d != 0 && lo <= hi) {
             if constexpr (lo == 0) acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1]);
             else acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1] - P[lo]);
-            opaque(acc);
         }
     });
     return acc;
 }
 
-struct C4Smem {
-    // ring slot: [L row: 64 bytes][R row: rwb bytes]; then the cost slice 64 x cspb
-    int slotb, rwb, cspb;
-};
+// ---------------------------------------------------------------------------------------------------------------------------
+// Prefix-form window sums (interior tiles).  In: the lane's T (sum of its four columns) and prefix sums P1..P3, one dword each
+// (two packed u16 or one u32).  Out: the window sums H0..H3 of its four columns.  With R = 4m + rho:
+//     H_q = S + [q < rho ? T(-m-1) - P_{q-rho+4}(-m-1) : -P_{q-rho}(-m)] + [q + rho > 3 ? T(m) + P_{q+rho-3}(m+1) : P_{q+rho+1}(m)]
+//     S   = T(-m) + ... + T(m-1)                                  (X(d) = X of lane t+d, P_0 = 0, P_4 = T)
+// Every line of the asm below is ONE VALU instruction: the neighbour-lane operand comes through the DPP row shift of
+// v_add_u32_dpp / v_sub_u32_dpp (bound_ctrl: a lane without a source reads 0; those lanes hold no valid output).
+// Measured on gfx950 (tools/probe/dpp_sub_probe.hip): v_sub_u32_dpp d, a, b computes a[shifted] - b and v_subrev_u32_dpp d, a, b
+// computes b[shifted] - a -- the "rev" form moves the DPP shift to the other operand, it does not make the UNSHIFTED operand the
+// minuend -- so "acc - x(d)" does not exist as one instruction (the compiler's own DPP fusion of such a subtract gives wrong
+// results for the same reason).  Every subtraction is therefore written  t = x(d) - acc;  H = y(e) - t  (= acc - x(d) + y(e)).
+// All sums are exact modulo 2^32 on the packed dword, so an intermediate that exceeds 16 bits in a half (or is "negative") is
+// harmless: the final value of each half is < 2^16 by the u16 condition 2*cap*block^2 < 65535.
+// The compiler does not know these are DPP instructions, so it inserts no wait states for the "VALU writes a VGPR -> a DPP
+// instruction reads it" hazard (2 wait states).  Only T and P1..P3 are ever read through DPP, never a value produced inside a
+// statement, and every statement starts with s_nop 1: whatever wrote them -- including a copy the register allocator may have put
+// right in front of the statement -- is then at least 2 wait states old.
+#define GIP_DPPM " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#ifndef GIP_DPP_HEAD
+#define GIP_DPP_HEAD "s_nop 1\n\t"
+#endif
+#define GIP_ADD_SHR(d, x, acc, n) "v_add_u32_dpp " d ", " x ", " acc " row_shr:" n GIP_DPPM   /* d = x(t-n) + acc */
+#define GIP_ADD_SHL(d, x, acc, n) "v_add_u32_dpp " d ", " x ", " acc " row_shl:" n GIP_DPPM   /* d = x(t+n) + acc */
+#define GIP_SUB_SHR(d, x, b, n) "v_sub_u32_dpp " d ", " x ", " b " row_shr:" n GIP_DPPM       /* d = x(t-n) - b   */
+#define GIP_SUB_SHL(d, x, b, n) "v_sub_u32_dpp " d ", " x ", " b " row_shl:" n GIP_DPPM       /* d = x(t+n) - b   */
+
+template <int R>
+__device__ __forceinline__ void hsum_pf(u32 T, u32 P1, u32 P2, u32 P3, u32& H0, u32& H1, u32& H2, u32& H3)
+{
+    constexpr int m = R / 4, rho = R % 4;
+    static_assert(R >= 2 && R <= 15, "block radius");
+    // operands: %0-%3 H0-H3, %4-%6 temporaries, then the inputs
+    u32 x, y, z;
+    if constexpr (m == 0 && rho == 2) {
+        // R = 2: H0 = T(-1) - P2(-1) + P3,  H1 = T(-1) - P3(-1) + T,  H2 = T + P1(1),  H3 = T - P1 + P2(1)       [%7 T, %8-%10 P1-P3]
+        asm(GIP_DPP_HEAD
+            GIP_SUB_SHR("%4", "%9", "%10", "1")       // x  = P2(-1) - P3
+            GIP_SUB_SHR("%5", "%10", "%7", "1")       // y  = P3(-1) - T
+            "v_sub_u32 %6, %7, %8\n\t"                // z  = T - P1
+            GIP_ADD_SHL("%2", "%8", "%7", "1")        // H2 = P1(1) + T
+            GIP_SUB_SHR("%0", "%7", "%4", "1")        // H0 = T(-1) - x
+            GIP_SUB_SHR("%1", "%7", "%5", "1")        // H1 = T(-1) - y
+            GIP_ADD_SHL("%3", "%9", "%6", "1")        // H3 = P2(1) + z
+            : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+            : "v"(T), "v"(P1), "v"(P2), "v"(P3));
+    } else if constexpr (m == 0) {
+        // R = 3: H0 = T(-1) - P1(-1) + T,  H1 = X - P2(-1) + P1(1),  H2 = X - P3(-1) + P2(1),  H3 = T + P3(1),  X = T + T(-1)
+        asm(GIP_DPP_HEAD
+            GIP_ADD_SHR("%4", "%7", "%7", "1")        // X  = T(-1) + T
+            GIP_SUB_SHR("%5", "%8", "%7", "1")        // y  = P1(-1) - T
+            GIP_ADD_SHL("%3", "%10", "%7", "1")       // H3 = P3(1) + T
+            GIP_SUB_SHR("%1", "%9", "%4", "1")        // H1 = P2(-1) - X
+            GIP_SUB_SHR("%2", "%10", "%4", "1")       // H2 = P3(-1) - X
+            GIP_SUB_SHR("%0", "%7", "%5", "1")        // H0 = T(-1) - y
+            GIP_SUB_SHL("%1", "%8", "%1", "1")        // H1 = P1(1) - H1
+            GIP_SUB_SHL("%2", "%9", "%2", "1")        // H2 = P2(1) - H2
+            : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+            : "v"(T), "v"(P1), "v"(P2), "v"(P3));
+    } else {
+        // S: the whole lanes -m .. m-1
+        u32 S;
+        if constexpr (m == 1) asm(GIP_DPP_HEAD GIP_ADD_SHR("%0", "%1", "%1", "1") : "=&v"(S) : "v"(T));
+        else if constexpr (m == 2)
+            asm(GIP_DPP_HEAD GIP_ADD_SHR("%0", "%1", "%1", "1") GIP_ADD_SHR("%0", "%1", "%0", "2") GIP_ADD_SHL("%0", "%1", "%0", "1") : "=&v"(S) : "v"(T));
+        else
+            asm(GIP_DPP_HEAD GIP_ADD_SHR("%0", "%1", "%1", "1") GIP_ADD_SHR("%0", "%1", "%0", "2") GIP_ADD_SHR("%0", "%1", "%0", "3")
+                GIP_ADD_SHL("%0", "%1", "%0", "1") GIP_ADD_SHL("%0", "%1", "%0", "2") : "=&v"(S) : "v"(T));
+        // inputs: %7 S, %8 T, %9-%11 P1-P3, %12 = m, %13 = m + 1
+        if constexpr (rho == 0)
+            // H0 = S + P1(m),  H1 = S - P1(-m) + P2(m),  H2 = S - P2(-m) + P3(m),  H3 = S - P3(-m) + T(m)
+            asm(GIP_DPP_HEAD
+                GIP_SUB_SHR("%1", "%9", "%7", "%12")      // H1 = P1(-m) - S
+                GIP_SUB_SHR("%2", "%10", "%7", "%12")     // H2 = P2(-m) - S
+                GIP_SUB_SHR("%3", "%11", "%7", "%12")     // H3 = P3(-m) - S
+                GIP_ADD_SHL("%0", "%9", "%7", "%12")      // H0 = P1(m) + S
+                GIP_SUB_SHL("%1", "%10", "%1", "%12")     // H1 = P2(m) - H1
+                GIP_SUB_SHL("%2", "%11", "%2", "%12")     // H2 = P3(m) - H2
+                GIP_SUB_SHL("%3", "%8", "%3", "%12")      // H3 = T(m) - H3
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+        else if constexpr (rho == 1)
+            // H0 = S + T(-m-1) - P3(-m-1) + P2(m),  H1 = S + P3(m),  H2 = S - P1(-m) + T(m),  H3 = S + T(m) - P2(-m) + P1(m+1)
+            asm(GIP_DPP_HEAD
+                GIP_ADD_SHR("%4", "%8", "%7", "%13")      // x  = T(-m-1) + S
+                GIP_ADD_SHL("%5", "%8", "%7", "%12")      // y  = T(m) + S
+                GIP_SUB_SHR("%2", "%9", "%7", "%12")      // H2 = P1(-m) - S
+                GIP_ADD_SHL("%1", "%11", "%7", "%12")     // H1 = P3(m) + S
+                GIP_SUB_SHR("%0", "%11", "%4", "%13")     // H0 = P3(-m-1) - x
+                GIP_SUB_SHR("%3", "%10", "%5", "%12")     // H3 = P2(-m) - y
+                GIP_SUB_SHL("%2", "%8", "%2", "%12")      // H2 = T(m) - H2
+                GIP_SUB_SHL("%0", "%10", "%0", "%12")     // H0 = P2(m) - H0
+                GIP_SUB_SHL("%3", "%9", "%3", "%13")      // H3 = P1(m+1) - H3
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+        else if constexpr (rho == 2)
+            // H0 = W - P2(-m-1) + P3(m),  H1 = W - P3(-m-1) + T(m),  H2 = U + P1(m+1),  H3 = U - P1(-m) + P2(m+1),  W = S + T(-m-1), U = S + T(m)
+            asm(GIP_DPP_HEAD
+                GIP_ADD_SHR("%4", "%8", "%7", "%13")      // W  = T(-m-1) + S
+                GIP_ADD_SHL("%5", "%8", "%7", "%12")      // U  = T(m) + S
+                GIP_SUB_SHR("%0", "%10", "%4", "%13")     // H0 = P2(-m-1) - W
+                GIP_SUB_SHR("%1", "%11", "%4", "%13")     // H1 = P3(-m-1) - W
+                GIP_SUB_SHR("%3", "%9", "%5", "%12")      // H3 = P1(-m) - U
+                GIP_ADD_SHL("%2", "%9", "%5", "%13")      // H2 = P1(m+1) + U
+                GIP_SUB_SHL("%0", "%11", "%0", "%12")     // H0 = P3(m) - H0
+                GIP_SUB_SHL("%1", "%8", "%1", "%12")      // H1 = T(m) - H1
+                GIP_SUB_SHL("%3", "%10", "%3", "%13")     // H3 = P2(m+1) - H3
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+        else
+            // H0 = W - P1(-m-1) + T(m),  H1 = X - P2(-m-1) + P1(m+1),  H2 = X - P3(-m-1) + P2(m+1),  H3 = U + P3(m+1),
+            // W = S + T(-m-1),  U = S + T(m),  X = W + T(m)
+            asm(GIP_DPP_HEAD
+                GIP_ADD_SHR("%4", "%8", "%7", "%13")      // W  = T(-m-1) + S
+                GIP_ADD_SHL("%5", "%8", "%7", "%12")      // U  = T(m) + S
+                GIP_ADD_SHL("%6", "%8", "%4", "%12")      // X  = T(m) + W
+                GIP_SUB_SHR("%0", "%9", "%4", "%13")      // H0 = P1(-m-1) - W
+                GIP_ADD_SHL("%3", "%11", "%5", "%13")     // H3 = P3(m+1) + U
+                GIP_SUB_SHR("%1", "%10", "%6", "%13")     // H1 = P2(-m-1) - X
+                GIP_SUB_SHR("%2", "%11", "%6", "%13")     // H2 = P3(-m-1) - X
+                GIP_SUB_SHL("%0", "%8", "%0", "%12")      // H0 = T(m) - H0
+                GIP_SUB_SHL("%1", "%9", "%1", "%13")      // H1 = P1(m+1) - H1
+                GIP_SUB_SHL("%2", "%10", "%2", "%13")     // H2 = P2(m+1) - H2
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+    }
+}
 
 // NW = wavefronts per workgroup.  NW = 1 is the layout described above.  With NW > 1 the waves of a workgroup work on the SAME
 // 64 columns and split the disparity range further (slice s = 4 * wave + lane / 16 of NS = 4 * NW slices): they share the row
 // ring and the cost slice, so the LDS per wave -- what limits the number of resident waves -- drops by NW, and so do the
 // vertical-sum registers per lane.  The price: real barriers, the winner keys / uniqueness counts of the waves are merged
 // through LDS, the texture sums are computed by every wave, and a wave finalises only 64 / NW pixels per row.
-template <int NG, int R, int NW>
-__global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
+//
+// PF: prefix form (interior tile) or column form (border tile); uniform per workgroup.
+template <int NG, int R, int NW, bool PF>
+__device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb)
 {
     constexpr int K = (R + 3) / 4;
     constexpr int NRING = 2 * R + 1;
@@ -132,7 +264,6 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
     constexpr int CSPB = 2 * NDISP + 16;        // bytes per column of the cost slice
     constexpr int NLD = (RWD + NT - 1) / NT;    // right-row dwords each thread stages per row
     constexpr int QPW = 4 / NW;                 // pixel columns q finalised per wave
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     u32* ring = (u32*)smem_raw;
     uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
     u32* xbest = (u32*)(cs + (size_t)64 * CSPB);   // [NW][16][4] winner keys of each wave   (NW > 1 only)
@@ -140,10 +271,6 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 
     const int tid = threadIdx.x, wave = tid >> 6;
     const int lane = tid & 63, t = lane & 15, sl = lane >> 4, s = 4 * wave + sl;
-    const int c0 = a.cbeg - 4 * K + blockIdx.x * (64 - 8 * K);   // relative column of lane t=0, q=0
-    const int ya = a.row0 + blockIdx.y * a.rows_per_chunk;
-    const int yb = min(ya + a.rows_per_chunk, a.row1);
-    if (ya >= yb) return;
 
     const uint8_t* Lb = a.L + blockIdx.z * a.img_bs;
     const uint8_t* Rb = a.R + blockIdx.z * a.img_bs;
@@ -177,9 +304,10 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
     // right image, clamped-column rule: window column cc reads right column rofs + clamp(cc, -rofs, w - ndisp - rofs) + d.
     // Every column of a lane's quad that is clamped lands on the same clamp column, and a partly clamped quad contains its
     // clamp column, so one window lane per lane (tw) and a byte position per column (psh = 8 * position) express the rule.
-    int tw;
-    u32 psh[4];
-    {
+    // Interior tiles (PF): tw = t, psh[q] = 8 q.
+    int tw = t;
+    u32 psh[4] = {0u, 8u, 16u, 24u};
+    if constexpr (!PF) {
         const int rlo = -a.rofs, rhi = a.w - a.ndisp - a.rofs;
         const int off0 = clampi(c0 + 4 * t, rlo, rhi) - c0;
         tw = off0 >> 2;
@@ -202,10 +330,11 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
     };
 
     // ---- state
-    // vertical column sums, 4 x u16 per (column q, group g), kept as 64-bit values so that v_mqsad accumulates in place in
-    // an aligned register pair (separate lo/hi arrays cost ~200 v_mov per row to assemble the pairs)
+    // PF:  V[j][g] = prefix sum over columns 0..j of the vertical column sums (V[3] = T), TV[j] likewise for |L - ftzero|
+    // !PF: V[q][g] = vertical column sum of column q
+    // 4 x u16 per entry, kept as 64-bit values so that v_mqsad accumulates in place in an aligned register pair
     u64 V[4][NG];
-    u32 TV[4];                    // vertical column sums of |L - ftzero|
+    u32 TV[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         TV[q] = 0;
@@ -213,38 +342,53 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
         for (int g = 0; g < NG; g++) V[q][g] = 0;
     }
     const u32 ft1 = (u32)(a.ftzero + 1);
+    const u32 ft4 = ft1 * 0x01010101u;
+    constexpr u32 PMASK[4] = {0x000000FFu, 0x0000FFFFu, 0x00FFFFFFu, 0xFFFFFFFFu};
 
-    auto add_row = [&](int yy) {
+    // A staged row as this lane needs it: its left dword and the NG + 1 dwords of its right-image window.  Reading a row from the
+    // LDS ring and using it are separate steps so that the reads can be issued well ahead of the v_mqsad that consume them: with
+    // two waves per SIMD an exposed LDS round trip is idle VALU time (SQ_WAIT_ANY, profiles/).
+    struct RowRegs { u32 lw; u32 rd[NG + 1]; };
+    auto read_row = [&](int yy) -> RowRegs {
         const u32* slot = ring + (yy % NRING) * SLOTD;
-        const u32 lw = slot[t];
+        RowRegs r;
+        r.lw = slot[t];
         const u32* rw = slot + 16 + tw + NG * s;
-        u32 rd[NG + 1];
 #pragma unroll
-        for (int i = 0; i <= NG; i++) rd[i] = rw[i];
+        for (int i = 0; i <= NG; i++) r.rd[i] = rw[i];
+        return r;
+    };
+    auto add_regs = [&](const RowRegs& r) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u32 lb = (lw >> (8 * q)) & 0xFFu;
-            const u32 ref = lb << psh[q];
-            TV[q] = __builtin_amdgcn_sad_u8(lb, ft1, TV[q]);
+            u32 ref;
+            if constexpr (PF) {
+                ref = r.lw & PMASK[q];
+                TV[q] = __builtin_amdgcn_sad_u8(ref, ft4 & PMASK[q], TV[q]);
+            } else {
+                const u32 lb = (r.lw >> (8 * q)) & 0xFFu;
+                ref = lb << psh[q];
+                TV[q] = __builtin_amdgcn_sad_u8(lb, ft1, TV[q]);
+            }
 #pragma unroll
-            for (int g = 0; g < NG; g++) V[q][g] = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, V[q][g]);
+            for (int g = 0; g < NG; g++) V[q][g] = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)r.rd[g + 1] << 32) | r.rd[g], ref, V[q][g]);
         }
     };
-    auto sub_row = [&](int yy) {
-        const u32* slot = ring + (yy % NRING) * SLOTD;
-        const u32 lw = slot[t];
-        const u32* rw = slot + 16 + tw + NG * s;
-        u32 rd[NG + 1];
-#pragma unroll
-        for (int i = 0; i <= NG; i++) rd[i] = rw[i];
+    auto sub_regs = [&](const RowRegs& r) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u32 lb = (lw >> (8 * q)) & 0xFFu;
-            const u32 ref = lb << psh[q];
-            TV[q] -= __builtin_amdgcn_sad_u8(lb, ft1, 0u);
+            u32 ref;
+            if constexpr (PF) {
+                ref = r.lw & PMASK[q];
+                TV[q] -= __builtin_amdgcn_sad_u8(ref, ft4 & PMASK[q], 0u);
+            } else {
+                const u32 lb = (r.lw >> (8 * q)) & 0xFFu;
+                ref = lb << psh[q];
+                TV[q] -= __builtin_amdgcn_sad_u8(lb, ft1, 0u);
+            }
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                const u64 tq = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)rd[g + 1] << 32) | rd[g], ref, 0ull);
+                const u64 tq = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)r.rd[g + 1] << 32) | r.rd[g], ref, 0ull);
                 // lane-wise V >= t, so two independent 32-bit subtracts are exact; a 64-bit subtract would chain every pair
                 // through VCC (v_sub_co / v_subb) and serialise the whole row
                 u32 lo, hi;
@@ -254,14 +398,20 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
             }
         }
     };
+    // Workgroup-wide ordering of the LDS traffic.  One wave per workgroup: the LDS executes a wave's instructions in issue order, so
+    // all that is needed is that the compiler keeps the program order of the accesses (no s_waitcnt drain, no s_barrier).
+    auto wg_sync = [&]() {
+        if constexpr (NW > 1 || !C4_NOSYNC) __syncthreads();
+        else asm volatile("" ::: "memory");
+    };
 
     // ---- warm-up: rows ya-R .. ya+R-1 enter the window
     for (int yy = ya - R; yy < ya + R; yy++) {
         prefetch(yy);
         commit(yy);
     }
-    __syncthreads();
-    for (int yy = ya - R; yy < ya + R; yy++) add_row(yy);
+    wg_sync();
+    for (int yy = ya - R; yy < ya + R; yy++) add_regs(read_row(yy));
     prefetch(ya + R);
 
     // the pixel this lane finalises: column 4t + qf.  One wave: qf = lane / 16.  NW waves: wave w takes q in [w*QPW, (w+1)*QPW),
@@ -277,56 +427,95 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
     uint8_t* csrow_w = cs + (size_t)t * CSPB + (size_t)(4 * NG * s) * 2;
     const uint8_t* csrow_r = cs + (size_t)(16 * qf + t) * CSPB;
 
+    // Software pipeline of one iteration (row y):
+    //   commit row y+R to the ring -> issue its LDS reads (A) and the global loads of row y+R+1 -> SUBTRACT row y-R-1, whose
+    //   registers (S) were read during the previous iteration -> add row y+R -> window sums / WTA -> issue the LDS reads of row
+    //   y-R (the next S; its slot is not overwritten before the next commit) -> merge, uniqueness, finalise, store.
+    RowRegs S = {};
     for (int y = ya; y < yb; y++) {
-        __syncthreads();          // single wave: orders the LDS traffic of the previous iteration before the slot is reused
+        wg_sync();                // every wave is done with the slot row y+R replaces (its reads are in S)
         commit(y + R);
-        __syncthreads();
+        wg_sync();
+        const RowRegs A = read_row(y + R);
         if (y + R + 1 < a.h) prefetch(y + R + 1);
-        add_row(y + R);
+        if (C4_PIPE && y > ya && !(C4_ABLATE & 1)) sub_regs(S);
+        add_regs(A);
 
         // ---- horizontal window sums, group keys, cost slice
         u32 best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         u32 gmin[4][NG];          // min cost of each group (for the uniqueness count)
+        u32 tsum_q[4];
+        // group key of one (column, group); the group's four costs go to the cost slice in 16-byte stores (two groups of one
+        // column per ds_write_b128: with CSPB = 4 (mod 32) dwords between lanes that store is bank-conflict free, an 8-byte one is not)
+        auto wta = [&](auto qv, int g, P2 H) {
+            constexpr int q = decltype(qv)::value;
+            u32 m = pk_min_u16(H.lo, H.hi);
+            u32 gm = umin(m & 0xFFFFu, m >> 16);
+            gmin[q][g] = gm;
+            best[q] = umin(best[q], (gm << 8) | (u32)(NG * s + g));
+        };
+        auto park = [&](auto qv, int g, P2 H0, P2 H1, bool two) {
+            constexpr int q = decltype(qv)::value;
+            if constexpr (C4_ABLATE & 4) return;
+            if (two) *(uint4*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint4(H0.lo, H0.hi, H1.lo, H1.hi);
+            else *(uint2*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint2(H0.lo, H0.hi);
+        };
+        auto window_sums = [&](int g, P2 (&H)[4]) {
+            if constexpr (C4_ABLATE & 2) {
+                static_for<0, 4>([&](auto qv) { constexpr int q = decltype(qv)::value; H[q] = P2{(u32)V[q][g], (u32)(V[q][g] >> 32)}; });
+            } else if constexpr (PF) {
+                hsum_pf<R>((u32)V[3][g], (u32)V[0][g], (u32)V[1][g], (u32)V[2][g], H[0].lo, H[1].lo, H[2].lo, H[3].lo);
+                hsum_pf<R>((u32)(V[3][g] >> 32), (u32)(V[0][g] >> 32), (u32)(V[1][g] >> 32), (u32)(V[2][g] >> 32), H[0].hi, H[1].hi, H[2].hi, H[3].hi);
+            } else {
+                P2 P[5];
+                P[0] = {0u, 0u};
+                P[1] = {(u32)V[0][g], (u32)(V[0][g] >> 32)};
+                P[2] = P[1] + P2{(u32)V[1][g], (u32)(V[1][g] >> 32)};
+                P[3] = P[2] + P2{(u32)V[2][g], (u32)(V[2][g] >> 32)};
+                P[4] = P[3] + P2{(u32)V[3][g], (u32)(V[3][g] >> 32)};
+                auto shift = [](auto dv, P2 v) -> P2 {
+                    constexpr int d = decltype(dv)::value;
+                    return P2{lane_at<d>(v.lo), lane_at<d>(v.hi)};
+                };
+                static_for<0, 4>([&](auto qv) { H[decltype(qv)::value] = hsum<R, decltype(qv)::value>(P, shift); });
+            }
+        };
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-            P2 P[5];
-            P[0] = {0u, 0u};
-            P[1] = {(u32)V[0][g], (u32)(V[0][g] >> 32)};
-            P[2] = P[1] + P2{(u32)V[1][g], (u32)(V[1][g] >> 32)};
-            P[3] = P[2] + P2{(u32)V[2][g], (u32)(V[2][g] >> 32)};
-            P[4] = P[3] + P2{(u32)V[3][g], (u32)(V[3][g] >> 32)};
-            auto shift = [](auto dv, P2 v) -> P2 {
-                constexpr int d = decltype(dv)::value;
-                return P2{lane_at<d>(v.lo), lane_at<d>(v.hi)};
-            };
+        for (int g = 0; g < NG; g += 2) {
+            const bool two = C4_B128 && g + 1 < NG;
+            P2 Ha[4], Hb[4] = {};
+            window_sums(g, Ha);
+            if (two) window_sums(g + 1, Hb);
             static_for<0, 4>([&](auto qv) {
                 constexpr int q = decltype(qv)::value;
-                const P2 H = hsum<R, q>(P, shift);
-                u32 m = pk_min_u16(H.lo, H.hi);
-                u32 gm = umin(m & 0xFFFFu, m >> 16);
-                gmin[q][g] = gm;
-                best[q] = umin(best[q], (gm << 8) | (u32)(NG * s + g));
-                *(uint2*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint2(H.lo, H.hi);
+                wta(qv, g, Ha[q]);
+                if (two) wta(qv, g + 1, Hb[q]);
+                park(qv, g, Ha[q], Hb[q], two);
             });
+            if (!C4_B128) g--;    // one group per step
         }
-        // texture sums (32-bit, same window)
-        u32 tsum_q[4];
-        {
+        if constexpr (PF) {
+            hsum_pf<R>(TV[3], TV[0], TV[1], TV[2], tsum_q[0], tsum_q[1], tsum_q[2], tsum_q[3]);
+        } else {
+            // texture sums (32-bit, same window)
             u32 P[5];
             P[0] = 0; P[1] = TV[0]; P[2] = P[1] + TV[1]; P[3] = P[2] + TV[2]; P[4] = P[3] + TV[3];
             auto shift = [](auto dv, u32 v) -> u32 { return lane_at<decltype(dv)::value>(v); };
             static_for<0, 4>([&](auto qv) { constexpr int q = decltype(qv)::value; tsum_q[q] = hsum<R, q>(P, shift); });
         }
+        // the row that leaves the window next: issue its LDS reads now, they are consumed at the top of the next iteration
+        if (C4_PIPE && y + 1 < yb) S = read_row(y - R);
         // merge the four disparity quarters (lanes t, t+16, t+32, t+48)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+            if constexpr (C4_ABLATE & 8) break;
             best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 16));
             best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 32));
         }
         if constexpr (NW > 1) {
             if (sl == 0) *(uint4*)(xbest + (wave * 16 + t) * 4) = make_uint4(best[0], best[1], best[2], best[3]);
         }
-        __syncthreads();          // cost slice (and the waves' keys) complete
+        wg_sync();                // cost slice (and the waves' keys) complete
         if constexpr (NW > 1) {
 #pragma unroll
             for (int w2 = 0; w2 < NW; w2++) {
@@ -344,12 +533,14 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
                 const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
 #pragma unroll
                 for (int g = 0; g < NG; g++) cnt[q] += (gmin[q][g] <= thr) ? 1u : 0u;
-                cnt[q] += (u32)__shfl_xor((int)cnt[q], 16);
-                cnt[q] += (u32)__shfl_xor((int)cnt[q], 32);
+                if constexpr (!(C4_ABLATE & 8)) {
+                    cnt[q] += (u32)__shfl_xor((int)cnt[q], 16);
+                    cnt[q] += (u32)__shfl_xor((int)cnt[q], 32);
+                }
             }
             if constexpr (NW > 1) {
                 if (sl == 0) *(uint4*)(xcnt + (wave * 16 + t) * 4) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
-                __syncthreads();          // a.uniq is uniform: every wave takes this branch
+                wg_sync();                // a.uniq is uniform: every wave takes this branch
                 cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
 #pragma unroll
                 for (int w2 = 0; w2 < NW; w2++) {
@@ -364,7 +555,8 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
         const int ngle = (int)(qf == 0 ? cnt[0] : qf == 1 ? cnt[1] : qf == 2 ? cnt[2] : cnt[3]);
         const int minsad = (int)(key >> 8), gstar = (int)(key & 0xFFu);
         int d_out = a.filtered;
-        {
+        if constexpr (C4_ABLATE & 16) d_out = minsad + gstar + tsum + ngle;
+        else {
             // The winner's group and its two neighbours in ONE LDS round trip: 12 costs as six packed dwords D0..D5, entry
             // 4 + k is the winner (k = first minimum inside its group), entries 3 + k / 5 + k its sub-pixel neighbours.
             // Groups beyond either end of the range read as 0xFFFF (never <= a threshold; a real cost is < 0xFFFF).
@@ -418,12 +610,31 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
             disp[(size_t)y * a.dpitch + a.lofs + c_out] = (int16_t)d_out;
             if (cost) cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
         }
-        sub_row(y - R);
+        if (!C4_PIPE && !(C4_ABLATE & 1)) sub_regs(read_row(y - R));
     }
 }
 
 template <int NG, int R, int NW>
-int launch_c4(const BmArgs& a, int batch, hipStream_t st)
+__global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
+{
+    constexpr int K = (R + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    const int c0 = a.cbeg - 4 * K + blockIdx.x * (64 - 8 * K);   // relative column of lane t=0, q=0
+    const int ya = a.row0 + blockIdx.y * a.rows_per_chunk;
+    const int yb = min(ya + a.rows_per_chunk, a.row1);
+    if (ya >= yb) return;
+    // interior tile: no column of the tile is touched by the right-image clamp (rofs + clamp(cc, -rofs, w - ndisp - rofs) + d)
+    const bool interior = c0 >= -a.rofs && c0 + 63 <= a.w - a.ndisp - a.rofs;
+#ifdef C4_NO_PF
+    bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb);
+#else
+    if (interior) bm_c4_tile<NG, R, NW, true>(a, smem_raw, c0, ya, yb);
+    else bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb);
+#endif
+}
+
+template <int NG, int R, int NW>
+int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
     constexpr int K = (R + 3) / 4;
     constexpr int NS = 4 * NW;
@@ -465,34 +676,36 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st)
     b.rows_per_chunk = (nrows + nch - 1) / nch;
     nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;
     if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    // the matcher may run on a stream of its own (BmLaunchCtx::matcher_stream), fenced by events on both sides
     hipStream_t ks = st;
-    if (g_bm_match_stream) {
-        ks = g_bm_match_stream;
-        GIP_HIP_CHECK(hipEventRecord(g_bm_fork, st));
-        GIP_HIP_CHECK(hipStreamWaitEvent(ks, g_bm_fork, 0));
+    const bool forked = ctx && ctx->matcher_stream && ctx->matcher_stream != st;
+    if (forked) {
+        ks = ctx->matcher_stream;
+        GIP_HIP_CHECK(hipEventRecord(ctx->fork, st));
+        GIP_HIP_CHECK(hipStreamWaitEvent(ks, ctx->fork, 0));
     }
-    if (g_bm_ev0) GIP_HIP_CHECK(hipEventRecord(g_bm_ev0, ks));
+    if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, ks));
     hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), dim3(ntiles, nch, batch), dim3(64 * NW), sh, ks, b);
     GIP_LAUNCH_CHECK();
-    if (g_bm_ev1) GIP_HIP_CHECK(hipEventRecord(g_bm_ev1, ks));
-    if (g_bm_match_stream) {
-        GIP_HIP_CHECK(hipEventRecord(g_bm_join, ks));
-        GIP_HIP_CHECK(hipStreamWaitEvent(st, g_bm_join, 0));
+    if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, ks));
+    if (forked) {
+        GIP_HIP_CHECK(hipEventRecord(ctx->join, ks));
+        GIP_HIP_CHECK(hipStreamWaitEvent(st, ctx->join, 0));
     }
     return GIP_OK;
 }
 
 template <int NG, int NW>
-int dispatch_r(const BmArgs& a, int batch, hipStream_t st, bool* handled)
+int dispatch_r(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx, bool* handled)
 {
     *handled = true;
     switch (a.wsz2) {
-    case 2: return launch_c4<NG, 2, NW>(a, batch, st);
-    case 3: return launch_c4<NG, 3, NW>(a, batch, st);
-    case 4: return launch_c4<NG, 4, NW>(a, batch, st);
-    case 5: return launch_c4<NG, 5, NW>(a, batch, st);
-    case 7: return launch_c4<NG, 7, NW>(a, batch, st);
-    case 10: return launch_c4<NG, 10, NW>(a, batch, st);
+    case 2: return launch_c4<NG, 2, NW>(a, batch, st, ctx);
+    case 3: return launch_c4<NG, 3, NW>(a, batch, st, ctx);
+    case 4: return launch_c4<NG, 4, NW>(a, batch, st, ctx);
+    case 5: return launch_c4<NG, 5, NW>(a, batch, st, ctx);
+    case 7: return launch_c4<NG, 7, NW>(a, batch, st, ctx);
+    case 10: return launch_c4<NG, 10, NW>(a, batch, st, ctx);
     default: *handled = false; return GIP_OK;
     }
 }
@@ -517,7 +730,7 @@ bool gip_bm_c4_can(const BmArgs& a)
     }
 }
 
-int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled)
+int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx, bool* handled)
 {
     *handled = false;
     if (!gip_bm_c4_can(a)) return GIP_OK;
@@ -533,15 +746,20 @@ int gip_bm_c4_launch(const BmArgs& a, int batch, hipStream_t st, bool* handled)
 #ifndef C4_NW_256
 #define C4_NW_256 4
 #endif
+#ifdef C4_ONLY_KITTI
+    if (a.ndisp == 128 && a.wsz2 == 4) { *handled = true; return launch_c4<8, 4, 1>(a, batch, st, ctx); }
+    return GIP_OK;
+#else
     switch (a.ndisp) {
-    case 16: return dispatch_r<1, 1>(a, batch, st, handled);
-    case 32: return dispatch_r<2, 1>(a, batch, st, handled);
-    case 48: return dispatch_r<3, 1>(a, batch, st, handled);
-    case 64: return dispatch_r<4, 1>(a, batch, st, handled);
-    case 96: return dispatch_r<6, 1>(a, batch, st, handled);
-    case 128: return dispatch_r<8 / C4_NW_128, C4_NW_128>(a, batch, st, handled);
-    case 192: return dispatch_r<12 / C4_NW_192, C4_NW_192>(a, batch, st, handled);
-    case 256: return dispatch_r<16 / C4_NW_256, C4_NW_256>(a, batch, st, handled);
+    case 16: return dispatch_r<1, 1>(a, batch, st, ctx, handled);
+    case 32: return dispatch_r<2, 1>(a, batch, st, ctx, handled);
+    case 48: return dispatch_r<3, 1>(a, batch, st, ctx, handled);
+    case 64: return dispatch_r<4, 1>(a, batch, st, ctx, handled);
+    case 96: return dispatch_r<6, 1>(a, batch, st, ctx, handled);
+    case 128: return dispatch_r<8 / C4_NW_128, C4_NW_128>(a, batch, st, ctx, handled);
+    case 192: return dispatch_r<12 / C4_NW_192, C4_NW_192>(a, batch, st, ctx, handled);
+    case 256: return dispatch_r<16 / C4_NW_256, C4_NW_256>(a, batch, st, ctx, handled);
     default: return GIP_OK;
     }
+#endif
 }

@@ -36,6 +36,17 @@ for i in range(N):
     run(i)
 torch.cuda.synchronize()
 print("outputs identical:", all(bool(torch.equal(outs[0], outs[i])) for i in range(1, N)))
+for i in range(1, N):
+    if not torch.equal(outs[0], outs[i]):
+        a, b = outs[0][0].cpu().numpy().astype(int), outs[i][0].cpu().numpy().astype(int)
+        bad = a != b
+        ys, xs = np.nonzero(bad)
+        print("  lib %d vs 0, image 0: %d of %d pixels differ; rows %d..%d cols %d..%d" % (i, bad.sum(), bad.size, ys.min(), ys.max(), xs.min(), xs.max()))
+        print("  columns with most mismatches:", sorted(((int(c), int(n)) for c, n in zip(*np.unique(xs, return_counts=True))), key=lambda t: -t[1])[:12])
+        print("  (x - lofs) mod 4 histogram:", np.bincount((xs - (ND - 1)) % 4, minlength=4).tolist())
+        print("  rows with most mismatches:", sorted(((int(c), int(n)) for c, n in zip(*np.unique(ys, return_counts=True))), key=lambda t: -t[1])[:8])
+        for k in range(min(6, len(ys))):
+            print("   (y=%d,x=%d): %d vs %d" % (ys[k], xs[k], a[ys[k], xs[k]], b[ys[k], xs[k]]))
 times = [[] for _ in range(N)]
 for rnd in range(12):
     for i in range(N):
