@@ -17,8 +17,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libgpuimageproc_hip.so")
-SOURCES = ["k_image.hip", "k_stereobm.hip", "k_stereobm_c4.hip", "k_stereobm_wide.hip", "k_post.hip", "gip_capi.hip", "gip_model.cpp"]
-HEADERS = [os.path.join(CSRC, "gip_internal.h"), os.path.join(CSRC, "gip_model.h"), os.path.join(CSRC, "bm_common.h"), os.path.join(ROOT, "include", "gpuimageproc_hip.h")]
+SOURCES = ["k_stereobm_c4_ra.hip", "k_stereobm_c4_rb.hip", "k_stereobm_c4_rc.hip", "k_stereobm_c4_rd.hip", "k_image.hip", "k_stereobm.hip", "k_stereobm_c4.hip",
+           "k_stereobm_wide.hip", "k_post.hip", "gip_capi.hip", "gip_model.cpp"]
+HEADERS = [os.path.join(CSRC, "gip_internal.h"), os.path.join(CSRC, "gip_model.h"), os.path.join(CSRC, "bm_common.h"), os.path.join(CSRC, "k_stereobm_c4_impl.h"),
+           os.path.join(ROOT, "include", "gpuimageproc_hip.h")]
 ARCH = os.environ.get("GIP_OFFLOAD_ARCH", "gfx950")
 # -ffp-contract=off: the float/double paths (disparity->f32, reprojection, colour ramp, remap tables) must round
 # exactly like the CPU oracle, so no mul+add fusion on either host or device.
@@ -54,7 +56,7 @@ def _compile(src, force):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     if force or _stale(LIB, objs):
         cmd = [hipcc(), "-shared", "--offload-arch=" + ARCH, "-o", LIB] + objs

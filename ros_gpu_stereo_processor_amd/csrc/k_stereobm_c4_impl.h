@@ -1,0 +1,736 @@
+// k_stereobm_c4_impl.h -- the main SAD block matcher for gfx950 ("column-sum" form), every output column.
+// (kernel template + launcher; instantiated for ranges of the block radius by k_stereobm_c4_r*.hip, dispatched by k_stereobm_c4.hip)
+//
+// Same semantics as k_stereobm.hip (cv::StereoBM, reference src/GPUStereoProcessor.cpp:312-321); different work mapping,
+// built around what the packed-byte SAD unit and the DPP cross-lane network of a CDNA4 wavefront do well:
+//
+//   * ONE WAVEFRONT = one tile of 64 image columns x a slice of the disparities, marching down its row chunk.
+//     lane = s*16 + t :  t in [0,16) owns the 4 adjacent columns 4t..4t+3,  s in [0,4) owns a quarter of the wave's disparity
+//     range (NG groups of 4 disparities).
+//   * INTERIOR tiles (no clamped column) keep, per (lane, group), the PREFIX sums over the lane's four columns of the vertical
+//     running column sums:  P1 = V0, P2 = V0+V1, P3 = V0+V1+V2, T = V0+V1+V2+V3  (V = sum over the 2r+1 window rows of |L - R|),
+//     each as 4 packed u16 in a 64-bit register pair.  A row entering the window is added by four v_mqsad_pk_u16_u8 whose
+//     reference dword is the lane's left-image dword with 1, 2, 3 and 4 LIVE bytes (a zero byte is masked; pixels are biased by +1
+//     so a real pixel is never zero): column q sits at byte q and reads byte i+q of the lane's aligned 8-byte right-image window
+//     for disparity i, so one instruction forms a whole prefix sum -- no byte shuffling, no prefix adds.  The row leaving the
+//     window is recomputed the same way and subtracted with two 32-bit subtracts (no borrow can cross the packed lanes).
+//   * The HORIZONTAL window sum of column q of lane t is then
+//         H_q = sum of T over the whole lanes inside the window  -  P_ja(lane of the first column)  +  P_jb+1(lane of the last)
+//     i.e. for block 9:  H0 = A + P1(t+1),  H1 = A - P1(t-1) + P2(t+1),  H2 = A - P2(t-1) + P3(t+1),  H3 = A - P3(t-1) + T(t+1),
+//     A = T + T(t-1):  8 instructions per dword, every one a v_add_u32_dpp / v_sub_u32_dpp that fetches its neighbour-lane
+//     operand through the DPP row shift (hsum_pf below; the column-wise form took 21 per dword; a subtraction is written
+//     t = x(d) - acc; H = y(e) - t  because the DPP subtract always has the SHIFTED operand as minuend).  Outputs are valid for lanes
+//     t in [K, 15-K], K = ceil(r/4); tiles advance by 64-8K columns.
+//   * BORDER tiles (the clamped-column rule of OpenCV applies somewhere in the tile) keep the four column sums V0..V3 themselves
+//     (one live reference byte per v_mqsad, byte position = clamped column) and form the window sums column-wise.
+//   * Winner-take-all: per 4-disparity group a packed min and one 32-bit key (cost << 8 | group); quarters are merged with
+//     two xor-shuffles.  The row's cost slice is parked in LDS; lane (s,t) then finalises pixel 4t+s: exact winner inside the
+//     group, sub-pixel neighbours, texture test and the uniqueness test (count of groups <= threshold vs the groups that
+//     touch the winner, then an exact check of those 12 costs).
+//   * Prefiltered rows are staged in an LDS ring of 2r+1 rows by the wave itself with aligned dword loads issued one row
+//     ahead (register prefetch), so global latency overlaps the SAD work.
+#pragma once
+#include "gip_internal.h"
+#include "bm_common.h"
+
+#include <cmath>
+#include <type_traits>
+#include <utility>
+
+// C4_ABLATE: bit mask for timing-only diagnostic builds (tools/ab_c4.sh): 1 no leaving-row subtract, 2 no window sums (costs = the
+// prefix sums themselves), 4 no cost-slice parking, 8 no quarter merges (ds_bpermute), 16 no finalisation.  Any bit set gives
+// WRONG disparities; the product build has none.
+#ifndef C4_ABLATE
+#define C4_ABLATE 0
+#endif
+// measured design switches (tools/ab_c4.sh, tools/bm_ab.py)
+#ifndef C4_PIPE     /* 1: subtract the leaving row at the top of the NEXT iteration from registers read before finalisation */
+#define C4_PIPE 0
+#endif
+#ifndef C4_B128     /* 1: park two groups per 16-byte LDS store */
+#define C4_B128 1
+#endif
+#ifndef C4_NOSYNC   /* 1: one-wave workgroups order their LDS traffic by program order only (no s_waitcnt drain) */
+#define C4_NOSYNC 1
+#endif
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ u32 umin(u32 a, u32 b) { return a < b ? a : b; }
+
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    us2 x = __builtin_bit_cast(us2, a), y = __builtin_bit_cast(us2, b);
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(x, y));
+}
+
+// value of lane (t + D) within the 16-lane DPP row; lanes without a source get 0
+template <int D>
+__device__ __forceinline__ u32 lane_at(u32 v)
+{
+    if constexpr (D == 0) return v;
+    else if constexpr (D < 0) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + (-D), 0xF, 0xF, true);  // row_shr:-D
+    else return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + D, 0xF, 0xF, true);                           // row_shl:D
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// packed pair (two dwords = 4 x u16) helpers
+struct P2 { u32 lo, hi; };
+__device__ __forceinline__ P2 operator+(P2 a, P2 b) { return {a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi - b.hi}; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Column-wise window sum (border tiles): output column q of this lane from the in-lane prefix sums P[0..4] (P[0] = 0):
+//   window = columns [4t+q-R, 4t+q+R];  lane t+d covers columns 4(t+d)..4(t+d)+3  ->  sub-columns [lo,hi]
+template <int R, int Q, class T, class SHIFT>
+__device__ __forceinline__ T hsum(const T (&P)[5], SHIFT&& shift)
+{
+    constexpr int K = (R + 3) / 4;
+    constexpr int lo0 = (Q - R) > 0 ? (Q - R) : 0;
+    constexpr int hi0 = (Q + R) < 3 ? (Q + R) : 3;
+    T acc{};
+    if constexpr (lo0 <= hi0) {
+        if constexpr (lo0 == 0) acc = P[hi0 + 1];
+        else acc = P[hi0 + 1] - P[lo0];
+    }
+    static_for<0, 2 * K + 1>([&](auto iv) {
+        constexpr int d = decltype(iv)::value - K;
+        constexpr int lo = (Q - R - 4 * d) > 0 ? (Q - R - 4 * d) : 0;
+        constexpr int hi = (Q + R - 4 * d) < 3 ? (Q + R - 4 * d) : 3;
+        if constexpr (d != 0 && lo <= hi) {
+            if constexpr (lo == 0) acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1]);
+            else acc = acc + shift(std::integral_constant<int, d>{}, P[hi + 1] - P[lo]);
+        }
+    });
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Prefix-form window sums (interior tiles).  In: the lane's T (sum of its four columns) and prefix sums P1..P3, one dword each
+// (two packed u16 or one u32).  Out: the window sums H0..H3 of its four columns.  With R = 4m + rho:
+//     H_q = S + [q < rho ? T(-m-1) - P_{q-rho+4}(-m-1) : -P_{q-rho}(-m)] + [q + rho > 3 ? T(m) + P_{q+rho-3}(m+1) : P_{q+rho+1}(m)]
+//     S   = T(-m) + ... + T(m-1)                                  (X(d) = X of lane t+d, P_0 = 0, P_4 = T)
+// Every line of the asm below is ONE VALU instruction: the neighbour-lane operand comes through the DPP row shift of
+// v_add_u32_dpp / v_sub_u32_dpp (bound_ctrl: a lane without a source reads 0; those lanes hold no valid output).
+// Measured on gfx950 (tools/probe/dpp_sub_probe.hip): v_sub_u32_dpp d, a, b computes a[shifted] - b and v_subrev_u32_dpp d, a, b
+// computes b[shifted] - a -- the "rev" form moves the DPP shift to the other operand, it does not make the UNSHIFTED operand the
+// minuend -- so "acc - x(d)" does not exist as one instruction (the compiler's own DPP fusion of such a subtract gives wrong
+// results for the same reason).  Every subtraction is therefore written  t = x(d) - acc;  H = y(e) - t  (= acc - x(d) + y(e)).
+// All sums are exact modulo 2^32 on the packed dword, so an intermediate that exceeds 16 bits in a half (or is "negative") is
+// harmless: the final value of each half is < 2^16 by the u16 condition 2*cap*block^2 < 65535.
+// The compiler does not know these are DPP instructions, so it inserts no wait states for the "VALU writes a VGPR -> a DPP
+// instruction reads it" hazard (2 wait states).  Only T and P1..P3 are ever read through DPP, never a value produced inside a
+// statement, and every statement starts with s_nop 1: whatever wrote them -- including a copy the register allocator may have put
+// right in front of the statement -- is then at least 2 wait states old.
+#define GIP_DPPM " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#ifndef GIP_DPP_HEAD
+#define GIP_DPP_HEAD "s_nop 1\n\t"
+#endif
+#define GIP_ADD_SHR(d, x, acc, n) "v_add_u32_dpp " d ", " x ", " acc " row_shr:" n GIP_DPPM   /* d = x(t-n) + acc */
+#define GIP_ADD_SHL(d, x, acc, n) "v_add_u32_dpp " d ", " x ", " acc " row_shl:" n GIP_DPPM   /* d = x(t+n) + acc */
+#define GIP_SUB_SHR(d, x, b, n) "v_sub_u32_dpp " d ", " x ", " b " row_shr:" n GIP_DPPM       /* d = x(t-n) - b   */
+#define GIP_SUB_SHL(d, x, b, n) "v_sub_u32_dpp " d ", " x ", " b " row_shl:" n GIP_DPPM       /* d = x(t+n) - b   */
+
+template <int R>
+__device__ __forceinline__ void hsum_pf(u32 T, u32 P1, u32 P2, u32 P3, u32& H0, u32& H1, u32& H2, u32& H3)
+{
+    constexpr int m = R / 4, rho = R % 4;
+    static_assert(R >= 2 && R <= 15, "block radius");
+    // operands: %0-%3 H0-H3, %4-%6 temporaries, then the inputs
+    u32 x, y, z;
+    if constexpr (m == 0 && rho == 2) {
+        // R = 2: H0 = T(-1) - P2(-1) + P3,  H1 = T(-1) - P3(-1) + T,  H2 = T + P1(1),  H3 = T - P1 + P2(1)       [%7 T, %8-%10 P1-P3]
+        asm(GIP_DPP_HEAD
+            GIP_SUB_SHR("%4", "%9", "%10", "1")       // x  = P2(-1) - P3
+            GIP_SUB_SHR("%5", "%10", "%7", "1")       // y  = P3(-1) - T
+            "v_sub_u32 %6, %7, %8\n\t"                // z  = T - P1
+            GIP_ADD_SHL("%2", "%8", "%7", "1")        // H2 = P1(1) + T
+            GIP_SUB_SHR("%0", "%7", "%4", "1")        // H0 = T(-1) - x
+            GIP_SUB_SHR("%1", "%7", "%5", "1")        // H1 = T(-1) - y
+            GIP_ADD_SHL("%3", "%9", "%6", "1")        // H3 = P2(1) + z
+            : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+            : "v"(T), "v"(P1), "v"(P2), "v"(P3));
+    } else if constexpr (m == 0) {
+        // R = 3: H0 = T(-1) - P1(-1) + T,  H1 = X - P2(-1) + P1(1),  H2 = X - P3(-1) + P2(1),  H3 = T + P3(1),  X = T + T(-1)
+        asm(GIP_DPP_HEAD
+            GIP_ADD_SHR("%4", "%7", "%7", "1")        // X  = T(-1) + T
+            GIP_SUB_SHR("%5", "%8", "%7", "1")        // y  = P1(-1) - T
+            GIP_ADD_SHL("%3", "%10", "%7", "1")       // H3 = P3(1) + T
+            GIP_SUB_SHR("%1", "%9", "%4", "1")        // H1 = P2(-1) - X
+            GIP_SUB_SHR("%2", "%10", "%4", "1")       // H2 = P3(-1) - X
+            GIP_SUB_SHR("%0", "%7", "%5", "1")        // H0 = T(-1) - y
+            GIP_SUB_SHL("%1", "%8", "%1", "1")        // H1 = P1(1) - H1
+            GIP_SUB_SHL("%2", "%9", "%2", "1")        // H2 = P2(1) - H2
+            : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+            : "v"(T), "v"(P1), "v"(P2), "v"(P3));
+    } else {
+        // S: the whole lanes -m .. m-1
+        u32 S;
+        if constexpr (m == 1) asm(GIP_DPP_HEAD GIP_ADD_SHR("%0", "%1", "%1", "1") : "=&v"(S) : "v"(T));
+        else if constexpr (m == 2)
+            asm(GIP_DPP_HEAD GIP_ADD_SHR("%0", "%1", "%1", "1") GIP_ADD_SHR("%0", "%1", "%0", "2") GIP_ADD_SHL("%0", "%1", "%0", "1") : "=&v"(S) : "v"(T));
+        else
+            asm(GIP_DPP_HEAD GIP_ADD_SHR("%0", "%1", "%1", "1") GIP_ADD_SHR("%0", "%1", "%0", "2") GIP_ADD_SHR("%0", "%1", "%0", "3")
+                GIP_ADD_SHL("%0", "%1", "%0", "1") GIP_ADD_SHL("%0", "%1", "%0", "2") : "=&v"(S) : "v"(T));
+        // inputs: %7 S, %8 T, %9-%11 P1-P3, %12 = m, %13 = m + 1
+        if constexpr (rho == 0)
+            // H0 = S + P1(m),  H1 = S - P1(-m) + P2(m),  H2 = S - P2(-m) + P3(m),  H3 = S - P3(-m) + T(m)
+            asm(GIP_DPP_HEAD
+                GIP_SUB_SHR("%1", "%9", "%7", "%12")      // H1 = P1(-m) - S
+                GIP_SUB_SHR("%2", "%10", "%7", "%12")     // H2 = P2(-m) - S
+                GIP_SUB_SHR("%3", "%11", "%7", "%12")     // H3 = P3(-m) - S
+                GIP_ADD_SHL("%0", "%9", "%7", "%12")      // H0 = P1(m) + S
+                GIP_SUB_SHL("%1", "%10", "%1", "%12")     // H1 = P2(m) - H1
+                GIP_SUB_SHL("%2", "%11", "%2", "%12")     // H2 = P3(m) - H2
+                GIP_SUB_SHL("%3", "%8", "%3", "%12")      // H3 = T(m) - H3
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+        else if constexpr (rho == 1)
+            // H0 = S + T(-m-1) - P3(-m-1) + P2(m),  H1 = S + P3(m),  H2 = S - P1(-m) + T(m),  H3 = S + T(m) - P2(-m) + P1(m+1)
+            asm(GIP_DPP_HEAD
+                GIP_ADD_SHR("%4", "%8", "%7", "%13")      // x  = T(-m-1) + S
+                GIP_ADD_SHL("%5", "%8", "%7", "%12")      // y  = T(m) + S
+                GIP_SUB_SHR("%2", "%9", "%7", "%12")      // H2 = P1(-m) - S
+                GIP_ADD_SHL("%1", "%11", "%7", "%12")     // H1 = P3(m) + S
+                GIP_SUB_SHR("%0", "%11", "%4", "%13")     // H0 = P3(-m-1) - x
+                GIP_SUB_SHR("%3", "%10", "%5", "%12")     // H3 = P2(-m) - y
+                GIP_SUB_SHL("%2", "%8", "%2", "%12")      // H2 = T(m) - H2
+                GIP_SUB_SHL("%0", "%10", "%0", "%12")     // H0 = P2(m) - H0
+                GIP_SUB_SHL("%3", "%9", "%3", "%13")      // H3 = P1(m+1) - H3
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+        else if constexpr (rho == 2)
+            // H0 = W - P2(-m-1) + P3(m),  H1 = W - P3(-m-1) + T(m),  H2 = U + P1(m+1),  H3 = U - P1(-m) + P2(m+1),  W = S + T(-m-1), U = S + T(m)
+            asm(GIP_DPP_HEAD
+                GIP_ADD_SHR("%4", "%8", "%7", "%13")      // W  = T(-m-1) + S
+                GIP_ADD_SHL("%5", "%8", "%7", "%12")      // U  = T(m) + S
+                GIP_SUB_SHR("%0", "%10", "%4", "%13")     // H0 = P2(-m-1) - W
+                GIP_SUB_SHR("%1", "%11", "%4", "%13")     // H1 = P3(-m-1) - W
+                GIP_SUB_SHR("%3", "%9", "%5", "%12")      // H3 = P1(-m) - U
+                GIP_ADD_SHL("%2", "%9", "%5", "%13")      // H2 = P1(m+1) + U
+                GIP_SUB_SHL("%0", "%11", "%0", "%12")     // H0 = P3(m) - H0
+                GIP_SUB_SHL("%1", "%8", "%1", "%12")      // H1 = T(m) - H1
+                GIP_SUB_SHL("%3", "%10", "%3", "%13")     // H3 = P2(m+1) - H3
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+        else
+            // H0 = W - P1(-m-1) + T(m),  H1 = X - P2(-m-1) + P1(m+1),  H2 = X - P3(-m-1) + P2(m+1),  H3 = U + P3(m+1),
+            // W = S + T(-m-1),  U = S + T(m),  X = W + T(m)
+            asm(GIP_DPP_HEAD
+                GIP_ADD_SHR("%4", "%8", "%7", "%13")      // W  = T(-m-1) + S
+                GIP_ADD_SHL("%5", "%8", "%7", "%12")      // U  = T(m) + S
+                GIP_ADD_SHL("%6", "%8", "%4", "%12")      // X  = T(m) + W
+                GIP_SUB_SHR("%0", "%9", "%4", "%13")      // H0 = P1(-m-1) - W
+                GIP_ADD_SHL("%3", "%11", "%5", "%13")     // H3 = P3(m+1) + U
+                GIP_SUB_SHR("%1", "%10", "%6", "%13")     // H1 = P2(-m-1) - X
+                GIP_SUB_SHR("%2", "%11", "%6", "%13")     // H2 = P3(-m-1) - X
+                GIP_SUB_SHL("%0", "%8", "%0", "%12")      // H0 = T(m) - H0
+                GIP_SUB_SHL("%1", "%9", "%1", "%13")      // H1 = P1(m+1) - H1
+                GIP_SUB_SHL("%2", "%10", "%2", "%13")     // H2 = P2(m+1) - H2
+                : "=&v"(H0), "=&v"(H1), "=&v"(H2), "=&v"(H3), "=&v"(x), "=&v"(y), "=&v"(z)
+                : "v"(S), "v"(T), "v"(P1), "v"(P2), "v"(P3), "n"(m), "n"(m + 1));
+    }
+}
+
+// NW = wavefronts per workgroup.  NW = 1 is the layout described above.  With NW > 1 the waves of a workgroup work on the SAME
+// 64 columns and split the disparity range further (slice s = 4 * wave + lane / 16 of NS = 4 * NW slices): they share the row
+// ring and the cost slice, so the LDS per wave -- what limits the number of resident waves -- drops by NW, and so do the
+// vertical-sum registers per lane.  The price: real barriers, the winner keys / uniqueness counts of the waves are merged
+// through LDS, the texture sums are computed by every wave, and a wave finalises only 64 / NW pixels per row.
+//
+// PF: prefix form (interior tile) or column form (border tile); uniform per workgroup.
+template <int NG, int R, int NW, bool PF>
+__device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb)
+{
+    constexpr int K = (R + 3) / 4;
+    constexpr int NRING = 2 * R + 1;
+    constexpr int NS = 4 * NW;                  // disparity slices
+    constexpr int NT = 64 * NW;                 // threads
+    constexpr int NDISP = 4 * NG * NS;
+    constexpr int RWD = 17 + NS * NG;           // right-row dwords needed per ring slot
+    constexpr int RWDP = (RWD + 3) & ~3;        // padded to 16 bytes
+    constexpr int SLOTD = 16 + RWDP;            // dwords per ring slot
+    constexpr int CSPB = 2 * NDISP + 16;        // bytes per column of the cost slice
+    constexpr int NLD = (RWD + NT - 1) / NT;    // right-row dwords each thread stages per row
+    constexpr int QPW = 4 / NW;                 // pixel columns q finalised per wave
+    u32* ring = (u32*)smem_raw;
+    uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
+    u32* xbest = (u32*)(cs + (size_t)64 * CSPB);   // [NW][16][4] winner keys of each wave   (NW > 1 only)
+    u32* xcnt = xbest + NW * 64;                    // [NW][16][4] uniqueness counts of each wave
+
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int lane = tid & 63, t = lane & 15, sl = lane >> 4, s = 4 * wave + sl;
+
+    const uint8_t* Lb = a.L + blockIdx.z * a.img_bs;
+    const uint8_t* Rb = a.R + blockIdx.z * a.img_bs;
+    int16_t* disp = (int16_t*)((uint8_t*)a.disp + blockIdx.z * a.disp_bs);
+    int32_t* cost = a.cost ? (int32_t*)((uint8_t*)a.cost + blockIdx.z * a.cost_bs) : nullptr;
+
+    // ---- row staging: aligned dword loads + funnel shift, clamped to the row's dword range (pitch % 4 == 0)
+    const int lcol0 = a.lofs + c0;   // absolute column of L ring byte 0
+    const int rcol0 = a.rofs + c0;   // absolute column of R ring byte 0
+    const int ndw = (int)(a.pitch >> 2);
+    const int lsh = lcol0 & 3, rsh = rcol0 & 3;
+    const int ldw = (lcol0 >> 2) + tid;  // (arithmetic shift: floor for negative columns)
+    const int rdw = (rcol0 >> 2) + tid;
+    auto fetch = [&](const uint8_t* base, int yy, int dw, int sh) -> u32 {
+        const u32* row = (const u32*)(base + (size_t)yy * a.pitch);
+        u32 lo = row[clampi(dw, 0, ndw - 1)], hi = row[clampi(dw + 1, 0, ndw - 1)];
+        u32 v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        return (v & 0x7F7F7F7Fu) + 0x01010101u;   // +1 bias (valid pixels are <= 2*cap <= 126)
+    };
+    // left image, byte-granular edge replication (clamped-column rule: left column = clamp(lofs + cc, 0, w - 1)); only the
+    // lanes whose quad straddles an image edge take the slow path
+    auto fetch_l = [&](int yy) -> u32 {
+        const int col = lcol0 + 4 * tid;
+        if (col >= 0 && col + 3 <= a.w - 1) return fetch(Lb, yy, ldw, lsh);
+        const uint8_t* row = Lb + (size_t)yy * a.pitch;
+        u32 v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) v |= (u32)row[clampi(col + j, 0, a.w - 1)] << (8 * j);
+        return (v & 0x7F7F7F7Fu) + 0x01010101u;
+    };
+    // right image, clamped-column rule: window column cc reads right column rofs + clamp(cc, -rofs, w - ndisp - rofs) + d.
+    // Every column of a lane's quad that is clamped lands on the same clamp column, and a partly clamped quad contains its
+    // clamp column, so one window lane per lane (tw) and a byte position per column (psh = 8 * position) express the rule.
+    // Interior tiles (PF): tw = t, psh[q] = 8 q.
+    int tw = t;
+    u32 psh[4] = {0u, 8u, 16u, 24u};
+    if constexpr (!PF) {
+        const int rlo = -a.rofs, rhi = a.w - a.ndisp - a.rofs;
+        const int off0 = clampi(c0 + 4 * t, rlo, rhi) - c0;
+        tw = off0 >> 2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) psh[q] = 8u * (u32)((clampi(c0 + 4 * t + q, rlo, rhi) - c0) & 3);
+    }
+    u32 pf_l = 0, pf_r[NLD];
+    auto prefetch = [&](int yy) {
+        if (tid < 16) pf_l = fetch_l(yy);
+#pragma unroll
+        for (int i = 0; i < NLD; i++)
+            if (tid + NT * i < RWD) pf_r[i] = fetch(Rb, yy, rdw + NT * i, rsh);
+    };
+    auto commit = [&](int yy) {
+        u32* slot = ring + (yy % NRING) * SLOTD;
+        if (tid < 16) slot[tid] = pf_l;
+#pragma unroll
+        for (int i = 0; i < NLD; i++)
+            if (tid + NT * i < RWD) slot[16 + tid + NT * i] = pf_r[i];
+    };
+
+    // ---- state
+    // PF:  V[j][g] = prefix sum over columns 0..j of the vertical column sums (V[3] = T), TV[j] likewise for |L - ftzero|
+    // !PF: V[q][g] = vertical column sum of column q
+    // 4 x u16 per entry, kept as 64-bit values so that v_mqsad accumulates in place in an aligned register pair
+    u64 V[4][NG];
+    u32 TV[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        TV[q] = 0;
+#pragma unroll
+        for (int g = 0; g < NG; g++) V[q][g] = 0;
+    }
+    const u32 ft1 = (u32)(a.ftzero + 1);
+    const u32 ft4 = ft1 * 0x01010101u;
+    constexpr u32 PMASK[4] = {0x000000FFu, 0x0000FFFFu, 0x00FFFFFFu, 0xFFFFFFFFu};
+
+    // A staged row as this lane needs it: its left dword and the NG + 1 dwords of its right-image window.  Reading a row from the
+    // LDS ring and using it are separate steps so that the reads can be issued well ahead of the v_mqsad that consume them: with
+    // two waves per SIMD an exposed LDS round trip is idle VALU time (SQ_WAIT_ANY, profiles/).
+    struct RowRegs { u32 lw; u32 rd[NG + 1]; };
+    auto read_row = [&](int yy) -> RowRegs {
+        const u32* slot = ring + (yy % NRING) * SLOTD;
+        RowRegs r;
+        r.lw = slot[t];
+        const u32* rw = slot + 16 + tw + NG * s;
+#pragma unroll
+        for (int i = 0; i <= NG; i++) r.rd[i] = rw[i];
+        return r;
+    };
+    auto add_regs = [&](const RowRegs& r) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 ref;
+            if constexpr (PF) {
+                ref = r.lw & PMASK[q];
+                TV[q] = __builtin_amdgcn_sad_u8(ref, ft4 & PMASK[q], TV[q]);
+            } else {
+                const u32 lb = (r.lw >> (8 * q)) & 0xFFu;
+                ref = lb << psh[q];
+                TV[q] = __builtin_amdgcn_sad_u8(lb, ft1, TV[q]);
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) V[q][g] = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)r.rd[g + 1] << 32) | r.rd[g], ref, V[q][g]);
+        }
+    };
+    auto sub_regs = [&](const RowRegs& r) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 ref;
+            if constexpr (PF) {
+                ref = r.lw & PMASK[q];
+                TV[q] -= __builtin_amdgcn_sad_u8(ref, ft4 & PMASK[q], 0u);
+            } else {
+                const u32 lb = (r.lw >> (8 * q)) & 0xFFu;
+                ref = lb << psh[q];
+                TV[q] -= __builtin_amdgcn_sad_u8(lb, ft1, 0u);
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const u64 tq = __builtin_amdgcn_mqsad_pk_u16_u8(((u64)r.rd[g + 1] << 32) | r.rd[g], ref, 0ull);
+                // lane-wise V >= t, so two independent 32-bit subtracts are exact; a 64-bit subtract would chain every pair
+                // through VCC (v_sub_co / v_subb) and serialise the whole row
+                u32 lo, hi;
+                asm("v_sub_u32 %0, %1, %2" : "=v"(lo) : "v"((u32)V[q][g]), "v"((u32)tq));
+                asm("v_sub_u32 %0, %1, %2" : "=v"(hi) : "v"((u32)(V[q][g] >> 32)), "v"((u32)(tq >> 32)));
+                V[q][g] = ((u64)hi << 32) | lo;
+            }
+        }
+    };
+    // Workgroup-wide ordering of the LDS traffic.  One wave per workgroup: the LDS executes a wave's instructions in issue order, so
+    // all that is needed is that the compiler keeps the program order of the accesses (no s_waitcnt drain, no s_barrier).
+    auto wg_sync = [&]() {
+        if constexpr (NW > 1 || !C4_NOSYNC) __syncthreads();
+        else asm volatile("" ::: "memory");
+    };
+
+    // ---- warm-up: rows ya-R .. ya+R-1 enter the window
+    for (int yy = ya - R; yy < ya + R; yy++) {
+        prefetch(yy);
+        commit(yy);
+    }
+    wg_sync();
+    for (int yy = ya - R; yy < ya + R; yy++) add_regs(read_row(yy));
+    prefetch(ya + R);
+
+    // the pixel this lane finalises: column 4t + qf.  One wave: qf = lane / 16.  NW waves: wave w takes q in [w*QPW, (w+1)*QPW),
+    // its lanes with lane / 16 >= QPW have no pixel.
+    const bool fin = sl < QPW;
+    const int qf = (wave * QPW + sl) & 3;
+    const int my_col = 4 * t + qf;
+    const int c_out = c0 + my_col;
+    const bool writer = fin && (t >= K) && (t <= 15 - K) && (c_out >= a.cbeg) && (c_out < a.cend);
+    // cost slice rows ordered [q][t] (row = 16q + t): the stores of consecutive lanes are CSPB = 4 (mod 32) dwords apart
+    // (bank-conflict free)
+    constexpr int QSTRIDE = 16 * CSPB;
+    uint8_t* csrow_w = cs + (size_t)t * CSPB + (size_t)(4 * NG * s) * 2;
+    const uint8_t* csrow_r = cs + (size_t)(16 * qf + t) * CSPB;
+
+    // Software pipeline of one iteration (row y):
+    //   commit row y+R to the ring -> issue its LDS reads (A) and the global loads of row y+R+1 -> SUBTRACT row y-R-1, whose
+    //   registers (S) were read during the previous iteration -> add row y+R -> window sums / WTA -> issue the LDS reads of row
+    //   y-R (the next S; its slot is not overwritten before the next commit) -> merge, uniqueness, finalise, store.
+    RowRegs S = {};
+    for (int y = ya; y < yb; y++) {
+        wg_sync();                // every wave is done with the slot row y+R replaces (its reads are in S)
+        commit(y + R);
+        wg_sync();
+        const RowRegs A = read_row(y + R);
+        if (y + R + 1 < a.h) prefetch(y + R + 1);
+        if (C4_PIPE && y > ya && !(C4_ABLATE & 1)) sub_regs(S);
+        add_regs(A);
+
+        // ---- horizontal window sums, group keys, cost slice
+        u32 best[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        u32 gmin[4][NG];          // min cost of each group (for the uniqueness count)
+        u32 tsum_q[4];
+        // group key of one (column, group); the group's four costs go to the cost slice in 16-byte stores (two groups of one
+        // column per ds_write_b128: with CSPB = 4 (mod 32) dwords between lanes that store is bank-conflict free, an 8-byte one is not)
+        auto wta = [&](auto qv, int g, P2 H) {
+            constexpr int q = decltype(qv)::value;
+            u32 m = pk_min_u16(H.lo, H.hi);
+            u32 gm = umin(m & 0xFFFFu, m >> 16);
+            gmin[q][g] = gm;
+            best[q] = umin(best[q], (gm << 8) | (u32)(NG * s + g));
+        };
+        auto park = [&](auto qv, int g, P2 H0, P2 H1, bool two) {
+            constexpr int q = decltype(qv)::value;
+            if constexpr (C4_ABLATE & 4) return;
+            if (two) *(uint4*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint4(H0.lo, H0.hi, H1.lo, H1.hi);
+            else *(uint2*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint2(H0.lo, H0.hi);
+        };
+        auto window_sums = [&](int g, P2 (&H)[4]) {
+            if constexpr (C4_ABLATE & 2) {
+                static_for<0, 4>([&](auto qv) { constexpr int q = decltype(qv)::value; H[q] = P2{(u32)V[q][g], (u32)(V[q][g] >> 32)}; });
+            } else if constexpr (PF) {
+                hsum_pf<R>((u32)V[3][g], (u32)V[0][g], (u32)V[1][g], (u32)V[2][g], H[0].lo, H[1].lo, H[2].lo, H[3].lo);
+                hsum_pf<R>((u32)(V[3][g] >> 32), (u32)(V[0][g] >> 32), (u32)(V[1][g] >> 32), (u32)(V[2][g] >> 32), H[0].hi, H[1].hi, H[2].hi, H[3].hi);
+            } else {
+                P2 P[5];
+                P[0] = {0u, 0u};
+                P[1] = {(u32)V[0][g], (u32)(V[0][g] >> 32)};
+                P[2] = P[1] + P2{(u32)V[1][g], (u32)(V[1][g] >> 32)};
+                P[3] = P[2] + P2{(u32)V[2][g], (u32)(V[2][g] >> 32)};
+                P[4] = P[3] + P2{(u32)V[3][g], (u32)(V[3][g] >> 32)};
+                auto shift = [](auto dv, P2 v) -> P2 {
+                    constexpr int d = decltype(dv)::value;
+                    return P2{lane_at<d>(v.lo), lane_at<d>(v.hi)};
+                };
+                static_for<0, 4>([&](auto qv) { H[decltype(qv)::value] = hsum<R, decltype(qv)::value>(P, shift); });
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            const bool two = C4_B128 && g + 1 < NG;
+            P2 Ha[4], Hb[4] = {};
+            window_sums(g, Ha);
+            if (two) window_sums(g + 1, Hb);
+            static_for<0, 4>([&](auto qv) {
+                constexpr int q = decltype(qv)::value;
+                wta(qv, g, Ha[q]);
+                if (two) wta(qv, g + 1, Hb[q]);
+                park(qv, g, Ha[q], Hb[q], two);
+            });
+            if (!C4_B128) g--;    // one group per step
+        }
+        if constexpr (PF) {
+            hsum_pf<R>(TV[3], TV[0], TV[1], TV[2], tsum_q[0], tsum_q[1], tsum_q[2], tsum_q[3]);
+        } else {
+            // texture sums (32-bit, same window)
+            u32 P[5];
+            P[0] = 0; P[1] = TV[0]; P[2] = P[1] + TV[1]; P[3] = P[2] + TV[2]; P[4] = P[3] + TV[3];
+            auto shift = [](auto dv, u32 v) -> u32 { return lane_at<decltype(dv)::value>(v); };
+            static_for<0, 4>([&](auto qv) { constexpr int q = decltype(qv)::value; tsum_q[q] = hsum<R, q>(P, shift); });
+        }
+        // the row that leaves the window next: issue its LDS reads now, they are consumed at the top of the next iteration
+        if (C4_PIPE && y + 1 < yb) S = read_row(y - R);
+        // merge the four disparity quarters (lanes t, t+16, t+32, t+48)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if constexpr (C4_ABLATE & 8) break;
+            best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 16));
+            best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 32));
+        }
+        if constexpr (NW > 1) {
+            if (sl == 0) *(uint4*)(xbest + (wave * 16 + t) * 4) = make_uint4(best[0], best[1], best[2], best[3]);
+        }
+        wg_sync();                // cost slice (and the waves' keys) complete
+        if constexpr (NW > 1) {
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) {
+                const uint4 o = *(const uint4*)(xbest + (w2 * 16 + t) * 4);
+                best[0] = umin(best[0], o.x); best[1] = umin(best[1], o.y); best[2] = umin(best[2], o.z); best[3] = umin(best[3], o.w);
+            }
+        }
+
+        // uniqueness: groups whose minimum is <= the per-column threshold, summed over the quarters
+        u32 cnt[4] = {0, 0, 0, 0};
+        if (a.uniq > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 ms = best[q] >> 8;
+                const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
+#pragma unroll
+                for (int g = 0; g < NG; g++) cnt[q] += (gmin[q][g] <= thr) ? 1u : 0u;
+                if constexpr (!(C4_ABLATE & 8)) {
+                    cnt[q] += (u32)__shfl_xor((int)cnt[q], 16);
+                    cnt[q] += (u32)__shfl_xor((int)cnt[q], 32);
+                }
+            }
+            if constexpr (NW > 1) {
+                if (sl == 0) *(uint4*)(xcnt + (wave * 16 + t) * 4) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+                wg_sync();                // a.uniq is uniform: every wave takes this branch
+                cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; w2++) {
+                    const uint4 o = *(const uint4*)(xcnt + (w2 * 16 + t) * 4);
+                    cnt[0] += o.x; cnt[1] += o.y; cnt[2] += o.z; cnt[3] += o.w;
+                }
+            }
+        }
+        // ---- finalise pixel (column 4t+qf) in this lane
+        const u32 key = qf == 0 ? best[0] : qf == 1 ? best[1] : qf == 2 ? best[2] : best[3];
+        const int tsum = (int)(qf == 0 ? tsum_q[0] : qf == 1 ? tsum_q[1] : qf == 2 ? tsum_q[2] : tsum_q[3]);
+        const int ngle = (int)(qf == 0 ? cnt[0] : qf == 1 ? cnt[1] : qf == 2 ? cnt[2] : cnt[3]);
+        const int minsad = (int)(key >> 8), gstar = (int)(key & 0xFFu);
+        int d_out = a.filtered;
+        if constexpr (C4_ABLATE & 16) d_out = minsad + gstar + tsum + ngle;
+        else {
+            // The winner's group and its two neighbours in ONE LDS round trip: 12 costs as six packed dwords D0..D5, entry
+            // 4 + k is the winner (k = first minimum inside its group), entries 3 + k / 5 + k its sub-pixel neighbours.
+            // Groups beyond either end of the range read as 0xFFFF (never <= a threshold; a real cost is < 0xFFFF).
+            constexpr int NGT = NS * NG;
+            const bool has_m = gstar > 0, has_p = gstar + 1 < NGT;
+            const uint2 gm_ = *(const uint2*)(csrow_r + (has_m ? gstar - 1 : gstar) * 8);
+            const uint2 g0_ = *(const uint2*)(csrow_r + gstar * 8);
+            const uint2 gp_ = *(const uint2*)(csrow_r + (has_p ? gstar + 1 : gstar) * 8);
+            const u32 D0 = has_m ? gm_.x : ~0u, D1 = has_m ? gm_.y : ~0u, D2 = g0_.x, D3 = g0_.y, D4 = has_p ? gp_.x : ~0u, D5 = has_p ? gp_.y : ~0u;
+            const u32 ms = (u32)minsad;
+            const u32 h1 = D1 >> 16, h2 = D2 & 0xFFFFu, h3 = D2 >> 16, h4 = D3 & 0xFFFFu, h5 = D3 >> 16, h6 = D4 & 0xFFFFu;
+            const int k = (h2 == ms) ? 0 : (h3 == ms) ? 1 : (h4 == ms) ? 2 : 3;   // first minimum
+            const int mind = 4 * gstar + k;
+            bool ok = tsum >= a.tex_thr;
+            if (a.uniq > 0) {
+                // exact part of the uniqueness test on the 12 costs, packed: "some u16 of x is <= thr"  <=>  pk_min(x, T1) != T1
+                // with T1 = thr + 1 in both halves
+                const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
+                const u32 t1 = umin(thr + 1u, 0xFFFFu), T1 = t1 | (t1 << 16);
+                const int touch_le = (pk_min_u16(pk_min_u16(D0, D1), T1) != T1) + (pk_min_u16(pk_min_u16(D2, D3), T1) != T1) +
+                                     (pk_min_u16(pk_min_u16(D4, D5), T1) != T1);
+                // blank entries 3+k .. 5+k (the winner and its neighbours): a 48-bit window sliding over (D1, D2, D3, D4)
+                const u64 wlo = 0xFFFFFFFFFFFF0000ull << (16 * k), whi = 0x0000FFFFFFFFFFFFull >> (16 * (3 - k));
+                const u32 E1 = D1 | (u32)wlo, E2 = D2 | (u32)(wlo >> 32), E3 = D3 | (u32)whi, E4 = D4 | (u32)(whi >> 32);
+                const u32 rest = pk_min_u16(pk_min_u16(pk_min_u16(D0, E1), pk_min_u16(E2, E3)), pk_min_u16(E4, D5));
+                const bool viol = pk_min_u16(rest, T1) != T1;
+                // a group that does not touch the winner lies entirely outside [mind-1, mind+1]
+                ok = ok && !viol && (ngle <= touch_le);
+            }
+            {
+                u32 n = k == 0 ? h1 : k == 1 ? h2 : k == 2 ? h3 : h4;
+                u32 p = k == 0 ? h3 : k == 1 ? h4 : k == 2 ? h5 : h6;
+                const u32 n0 = n;
+                if (mind == 0) n = p;                    // OpenCV: the missing neighbour is replaced by the other one
+                if (mind + 1 == NDISP) p = n0;
+                // (p - n) * 256 / den, C truncation; den = 2 * (max(p, n) - minsad) >= 2 |p - n|, so |quotient| <= 128 and
+                // |p - n| * 256 < 2^24: one float reciprocal plus a one-step correction is exact
+                const u32 ad = p > n ? p - n : n - p;
+                const u32 den = p + n - 2u * ms + ad;
+                const u32 num = ad << 8;
+                u32 q0 = (u32)((float)num * __frcp_rn((float)den));
+                const int r = (int)(num - q0 * den);
+                q0 += (r >= (int)den) ? 1u : 0u;
+                q0 -= (r < 0) ? 1u : 0u;
+                const int quot = den != 0 ? (p >= n ? (int)q0 : -(int)q0) : 0;
+                const int v = (NDISP - mind - 1 + a.mindisp) * 256 + quot + 15;
+                if (ok) d_out = v >> 4;
+            }
+        }
+        if (writer) {
+            disp[(size_t)y * a.dpitch + a.lofs + c_out] = (int16_t)d_out;
+            if (cost) cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
+        }
+        if (!C4_PIPE && !(C4_ABLATE & 1)) sub_regs(read_row(y - R));
+    }
+}
+
+template <int NG, int R, int NW>
+__global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
+{
+    constexpr int K = (R + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    const int c0 = a.cbeg - 4 * K + blockIdx.x * (64 - 8 * K);   // relative column of lane t=0, q=0
+    const int ya = a.row0 + blockIdx.y * a.rows_per_chunk;
+    const int yb = min(ya + a.rows_per_chunk, a.row1);
+    if (ya >= yb) return;
+    // interior tile: no column of the tile is touched by the right-image clamp (rofs + clamp(cc, -rofs, w - ndisp - rofs) + d)
+    const bool interior = c0 >= -a.rofs && c0 + 63 <= a.w - a.ndisp - a.rofs;
+#ifdef C4_NO_PF
+    bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb);
+#else
+    if (interior) bm_c4_tile<NG, R, NW, true>(a, smem_raw, c0, ya, yb);
+    else bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb);
+#endif
+}
+
+template <int NG, int R, int NW>
+int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
+{
+    constexpr int K = (R + 3) / 4;
+    constexpr int NS = 4 * NW;
+    constexpr int RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
+    const size_t sh = (size_t)(2 * R + 1) * SLOTD * 4 + (size_t)64 * (2 * 4 * NG * NS + 16) + (size_t)2 * NW * 64 * 4;
+    const int ncols = a.cend - a.cbeg;
+    const int ntiles = (ncols + (64 - 8 * K) - 1) / (64 - 8 * K);
+    const int nrows = a.row1 - a.row0;
+    // Row chunks.  A CU holds min(32 / NW, floor(160 KiB / LDS per workgroup)) workgroups.  Pick the chunk count that
+    // minimises  rounds x (rows per chunk + warm-up cost): whole "rounds" of resident workgroups matter because a partially
+    // filled last round idles most of the chip, and every chunk re-reads 2R warm-up rows (each worth about 0.4 of a full row:
+    // SAD only, no winner-take-all).
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+        else n_cu = 256;
+    }
+    int per_cu = (int)((160 * 1024) / (sh ? sh : 1));
+    if (per_cu > 32 / NW) per_cu = 32 / NW;
+    if (per_cu < 1) per_cu = 1;
+#ifdef C4_FIXED_CHUNKS
+    int nch = C4_FIXED_CHUNKS;
+#else
+    const double capacity = (double)n_cu * per_cu;
+    int nch = 1;
+    double best_cost = 1e300;
+    const int max_nch = nrows / (2 * R + 2) > 0 ? nrows / (2 * R + 2) : 1;
+    for (int c = 1; c <= max_nch && c <= 64; c++) {
+        const int rpc = (nrows + c - 1) / c;
+        const int real_c = (nrows + rpc - 1) / rpc;
+        const double wgs = (double)ntiles * real_c * batch;
+        const double rounds = wgs / capacity < 1.0 ? 1.0 : ceil(wgs / capacity - 1e-9);
+        const double cost = rounds * (rpc + 0.4 * 2 * R);
+        if (cost < best_cost - 1e-9) { best_cost = cost; nch = real_c; }
+    }
+#endif
+    BmArgs b = a;
+    b.rows_per_chunk = (nrows + nch - 1) / nch;
+    nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;
+    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    // the matcher may run on a stream of its own (BmLaunchCtx::matcher_stream), fenced by events on both sides
+    hipStream_t ks = st;
+    const bool forked = ctx && ctx->matcher_stream && ctx->matcher_stream != st;
+    if (forked) {
+        ks = ctx->matcher_stream;
+        GIP_HIP_CHECK(hipEventRecord(ctx->fork, st));
+        GIP_HIP_CHECK(hipStreamWaitEvent(ks, ctx->fork, 0));
+    }
+    if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, ks));
+    hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), dim3(ntiles, nch, batch), dim3(64 * NW), sh, ks, b);
+    GIP_LAUNCH_CHECK();
+    if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, ks));
+    if (forked) {
+        GIP_HIP_CHECK(hipEventRecord(ctx->join, ks));
+        GIP_HIP_CHECK(hipStreamWaitEvent(st, ctx->join, 0));
+    }
+    return GIP_OK;
+}
+
+// (groups per slice, waves) for a disparity count: ndisp = 16 * NG * NW.  The wave counts are measured choices (tools/bm_ab.py,
+// DESIGN.md 3.1): 2 or 4 waves are 12 % slower at ndisp 128 (any batch size), 2 waves are 38 % faster at ndisp 192 (4 waves: 28 %),
+// 4 waves 25 % faster at ndisp 256 (2 waves: 12 %); the other multiples of 16 take one wave when ndisp / 16 is odd or <= 8.
+template <int R>
+int dispatch_ndisp(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx, bool* handled)
+{
+    *handled = true;
+    switch (a.ndisp) {
+    case 16: return launch_c4<1, R, 1>(a, batch, st, ctx);
+    case 32: return launch_c4<2, R, 1>(a, batch, st, ctx);
+    case 48: return launch_c4<3, R, 1>(a, batch, st, ctx);
+    case 64: return launch_c4<4, R, 1>(a, batch, st, ctx);
+    case 80: return launch_c4<5, R, 1>(a, batch, st, ctx);
+    case 96: return launch_c4<6, R, 1>(a, batch, st, ctx);
+    case 112: return launch_c4<7, R, 1>(a, batch, st, ctx);
+    case 128: return launch_c4<8, R, 1>(a, batch, st, ctx);
+    case 144: return launch_c4<9, R, 1>(a, batch, st, ctx);
+    case 160: return launch_c4<5, R, 2>(a, batch, st, ctx);
+    case 176: return launch_c4<11, R, 1>(a, batch, st, ctx);
+    case 192: return launch_c4<6, R, 2>(a, batch, st, ctx);
+    case 208: return launch_c4<13, R, 1>(a, batch, st, ctx);
+    case 224: return launch_c4<7, R, 2>(a, batch, st, ctx);
+    case 240: return launch_c4<15, R, 1>(a, batch, st, ctx);
+    case 256: return launch_c4<4, R, 4>(a, batch, st, ctx);
+    default: *handled = false; return GIP_OK;
+    }
+}
+
+}  // namespace
+
+#define GIP_C4_RANGE_TU(NAME, ...)                                                                                             \
+    int NAME(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx, bool* handled)                                \
+    {                                                                                                                          \
+        *handled = false;                                                                                                      \
+        switch (a.wsz2) { __VA_ARGS__ default: return GIP_OK; }                                                                \
+    }
+#define GIP_C4_CASE(R) case R: return dispatch_ndisp<R>(a, batch, st, ctx, handled);

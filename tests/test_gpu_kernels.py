@@ -147,6 +147,21 @@ BM_CASES = [
     (500, 40, 192, 9, -16, 10, 15, 1),   # ndisp 192 = two waves per workgroup, negative minDisparity (clamped right-image columns)
     (500, 40, 192, 11, 5, 10, 0, 1),     # ... positive minDisparity, uniqueness test off (no count exchange between the waves)
     (340, 36, 256, 15, 0, 0, 25, 0),     # ndisp 256, width1 = 85: a single tile whose clamped borders meet
+    # every block radius 2..15 of the prefix-form window sums (R = 4m + rho: one asm template per rho, one core per m) and every
+    # (groups, waves) split of the disparity range, incl. the reference constructor's createStereoBM(48, 19) (GPUStereoProcessor.cpp:18-20)
+    (400, 60, 48, 19, 0, 3, 0, 0),       # R 9  (m 2, rho 1), the reference default
+    (330, 44, 80, 13, 0, 10, 15, 1),     # R 6  (m 1, rho 2), NG 5
+    (330, 44, 112, 17, 0, 10, 15, 1),    # R 8  (m 2, rho 0), NG 7
+    (420, 40, 144, 7, 0, 10, 15, 1),     # R 3  (m 0, rho 3), NG 9
+    (420, 44, 160, 23, 0, 10, 15, 1),    # R 11 (m 2, rho 3), two waves x NG 5
+    (420, 48, 176, 25, 0, 10, 15, 1),    # R 12 (m 3, rho 0), NG 11
+    (460, 52, 208, 27, 0, 10, 15, 1),    # R 13 (m 3, rho 1), NG 13
+    (460, 56, 224, 29, -7, 10, 15, 1),   # R 14 (m 3, rho 2), two waves x NG 7, negative minDisparity
+    (480, 40, 240, 5, 3, 10, 15, 1),     # R 2  (m 0, rho 2), NG 15, positive minDisparity
+    (300, 44, 64, 19, 0, 10, 15, 1),     # R 9 with the L/R check
+    (300, 44, 32, 21, 0, 10, 15, 1),     # R 10 (m 2, rho 2)
+    (300, 44, 32, 11, 0, 10, 15, 1),     # R 5  (m 1, rho 1)
+    (300, 44, 32, 15, 0, 10, 15, 1),     # R 7  (m 1, rho 3)
 ]
 
 

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Fast variant build for matcher experiments: recompiles ONLY k_stereobm_c4.hip with the given flags and links it with the other
+# Fast variant build for matcher experiments: recompiles ONLY k_stereobm_c4_ra.hip (block radius 2..4: the KITTI shape) with the given flags and links it with the other
 # objects of the normal build (ros_gpu_stereo_processor_amd/lib/obj).  usage: tools/ab_c4.sh <tag> [extra hipcc flags]
 set -e
 TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OBJ=$ROOT/ros_gpu_stereo_processor_amd/lib/obj; OUT=$ROOT/tools/ab; mkdir -p $OUT
 hipcc -c --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-unused-function "$@" -I $ROOT/include -I $ROOT/ros_gpu_stereo_processor_amd/csrc \
-  $ROOT/ros_gpu_stereo_processor_amd/csrc/k_stereobm_c4.hip -o $OUT/c4_$TAG.o
-hipcc -shared --offload-arch=gfx950 -o $OUT/lib_$TAG.so $OUT/c4_$TAG.o $(ls $OBJ/*.o | grep -v k_stereobm_c4.o)
+  $ROOT/ros_gpu_stereo_processor_amd/csrc/k_stereobm_c4_ra.hip -o $OUT/c4_$TAG.o
+hipcc -shared --offload-arch=gfx950 -o $OUT/lib_$TAG.so $OUT/c4_$TAG.o $(ls $OBJ/*.o | grep -v k_stereobm_c4_ra.o)
 echo built $OUT/lib_$TAG.so
