@@ -190,6 +190,8 @@ def main():
                     "matcher on its own stream (better for the large-disparity workloads)")
     ap.add_argument("--alone", action="store_true", help="also time the dominant kernel with nothing else in flight (three extra untimed steps) "
                     "and derive roofline.valu_model from it; implied by --depth 1")
+    ap.add_argument("--fused-front-end", action="store_true", help="rectify + XSOBEL as ONE pass raw -> prefiltered plane (gipk_rectify_xsobel) instead of remap, then prefilter "
+                    "(bit-identical; measured slower on MI355X, DESIGN.md 3.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     args = ap.parse_args()
@@ -227,7 +229,8 @@ def main():
     calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
     params = capi.BMParams(**bm_kwargs())
     outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
-    pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True) for _ in range(max(1, args.depth))]
+    pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True, fused_front_end=args.fused_front_end)
+             for _ in range(max(1, args.depth))]
     streams = [torch.cuda.Stream(device=dev) for _ in pipes]
     matcher_stream = torch.cuda.Stream(device=dev) if (len(pipes) > 1 and shared_matcher) else None
     for p in pipes:

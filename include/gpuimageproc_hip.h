@@ -281,6 +281,15 @@ int gipk_prefilter(const uint8_t *src, size_t src_pitch, uint8_t *dst, size_t ds
                    int prefilter_size, int prefilter_cap, int batch, size_t src_bstride, size_t dst_bstride,
                    gip_stream stream);
 
+/* Fused front end of the matcher: rectify (INTER_LINEAR remap, as gipk_remap_u8) and StereoBM's XSOBEL prefilter in ONE pass, raw
+ * mono image -> prefiltered plane; `rectified` (may be NULL) also receives the rectified image.  Replaces rectifyImage followed by
+ * the prefilter inside cv::StereoBM::compute (reference src/GPUStereoProcessor.cpp:236-250, :312-321); bit-exact with
+ * gipk_remap_u8 + gipk_prefilter(XSOBEL). */
+int gipk_rectify_xsobel(const uint8_t *src, size_t src_pitch, int sw, int sh, uint8_t *prefiltered, size_t pf_pitch,
+                        uint8_t *rectified, size_t rect_pitch, int w, int h, const int16_t *map1, const uint16_t *map2,
+                        int prefilter_cap, int batch, size_t src_bstride, size_t pf_bstride, size_t rect_bstride,
+                        gip_stream stream);
+
 /* Block matching on PREFILTERED images: SAD + WTA + texture + uniqueness + sub-pixel -> int16 x16 and (optional) the
  * min-SAD plane, i.e. the state findStereoCorrespondenceBM leaves before validateDisparity / ROI blanking. */
 int gipk_bm_match(const uint8_t *left, const uint8_t *right, size_t pitch, int w, int h, const gip_bm_params *p, int16_t *disp,
@@ -338,6 +347,9 @@ typedef struct gip_batch_desc {
                                 * fenced by events on both sides.  Pipelines that keep several batches in flight pass ONE
                                 * shared stream here: the matchers then run back to back instead of time-sharing, which is what
                                 * keeps the batches from falling into lock step */
+    int32_t fused_front_end;   /* 1: rectify + XSOBEL prefilter run as ONE pass raw -> prefiltered plane (gipk_rectify_xsobel) where the
+                                * configuration allows (XSOBEL, distorted camera); 0 (default): remap, then prefilter.  Bit-identical
+                                * results; the two-pass form is the faster one on MI355X, so it is the default */
 } gip_batch_desc;
 int gip_batch_set_maps_device(gip_handle h, int width, int height, const int16_t *map1_l, const uint16_t *map2_l,
                               const int16_t *map1_r, const uint16_t *map2_r);

@@ -80,7 +80,7 @@ class PointCloud2Msg(C.Structure):
 class BatchDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32),
                 ("left_raw", C.c_void_p), ("right_raw", C.c_void_p), ("disparity", C.c_void_p), ("disparity_f32", C.c_void_p),
-                ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p)]
+                ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p), ("fused_front_end", C.c_int32)]
 
 
 IMAGE_CB = C.CFUNCTYPE(None, C.POINTER(ImageMsg), C.c_void_p)
@@ -153,6 +153,7 @@ PROTOTYPES = {
     "gipk_remap_u8": (_i, [_vp, _sz, _i, _i, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _sz, _sz, _vp]),
     "gipk_remap_u8_interp": (_i, [_vp, _sz, _i, _i, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _i, _sz, _sz, _vp]),
     "gipk_prefilter": (_i, [_vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i, _sz, _sz, _vp]),
+    "gipk_rectify_xsobel": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp, _sz, _i, _i, _vp, _vp, _i, _i, _sz, _sz, _sz, _vp]),
     "gipk_bm_match": (_i, [_vp, _vp, _sz, _i, _i, C.POINTER(BMParams), _vp, _sz, _vp, _sz, _i, _sz, _sz, _sz, _vp]),
     "gipk_bm_finalize": (_i, [_vp, _sz, _vp, _sz, _i, _i, C.POINTER(BMParams), _i, _sz, _sz, _vp]),
     "gipk_stereobm_scratch_bytes": (_sz, [_i, _i, _i, C.POINTER(BMParams)]),

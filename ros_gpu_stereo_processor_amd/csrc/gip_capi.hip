@@ -1107,16 +1107,31 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         }
     }
     (void)raw_cn;
-    // stage 2: rectify (StereoProcessor.cpp:220-256)
+    // stage 2: rectify (StereoProcessor.cpp:220-256) + the matcher's prefilter.  gip_batch_desc::fused_front_end selects the
+    // one-pass form raw -> prefiltered plane (k_rectify_xsobel; the rectified plane is then written only where something else reads
+    // it: the left one, as the cloud's colour for mono input); NORMALIZED_RESPONSE / undistorted cameras always take two passes.
     // rectified mono planes: rows padded to 64 bytes so the prefilter can work on aligned dwords
     const size_t rp = gip_align_up((size_t)w, 64), rplane = rp * hh;
+    B_STEP(ensure_dev(h, h->bm_scratch, gipk_stereobm_scratch_bytes(w, hh, B, &bp)), "batch buffers");
+    uint8_t* pf[2];
+    size_t pfp = 0, pfplane = 0;
+    gip_stereobm_planes(h->bm_scratch.p, w, hh, B, &pf[0], &pf[1], &pfp, &pfplane);
+    const bool need_rect_l = want_pc && !color_l;     // mono input: the rectified left image colours the cloud
+    bool fused[2] = {false, false};
     for (int i = 0; i < 2; i++) {
-        B_STEP(ensure_dev(h, h->b_rect[i], rplane * B), "batch buffers");
         const GipPinhole& cam = i == 0 ? h->model.left : h->model.right;
-        if (cam.distorted)
+        const bool need_rect = i == 0 && need_rect_l;
+        fused[i] = cam.distorted && bp.prefilter_type == GIP_PREFILTER_XSOBEL && d->fused_front_end;
+        if (need_rect || !fused[i]) B_STEP(ensure_dev(h, h->b_rect[i], rplane * B), "batch buffers");
+        if (fused[i])
+            B_STEP(gipk_rectify_xsobel(mono[i], w, w, hh, pf[i], pfp, need_rect ? (uint8_t*)h->b_rect[i].p : nullptr, rp, w, hh, h->d_map1[i], h->d_map2[i], bp.prefilter_cap, B, npx,
+                                       pfplane, rplane, st), "rectify + prefilter");
+        else if (cam.distorted)
             B_STEP(gipk_remap_u8(mono[i], w, w, hh, (uint8_t*)h->b_rect[i].p, rp, w, hh, 1, h->d_map1[i], h->d_map2[i], B, npx, rplane, st), "rectify");
         else
             H_HIP(h, hipMemcpy2DAsync(h->b_rect[i].p, rp, mono[i], w, w, (size_t)hh * B, hipMemcpyDeviceToDevice, st));
+        if (!fused[i])
+            B_STEP(gipk_prefilter((const uint8_t*)h->b_rect[i].p, rp, pf[i], pfp, w, hh, bp.prefilter_type, bp.prefilter_size, bp.prefilter_cap, B, rplane, pfplane, st), "prefilter");
     }
     const uint8_t* rect_color = nullptr;
     int rect_color_cn = 3;
@@ -1136,7 +1151,6 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         }
     }
     // stage 3: disparity + speckle (StereoProcessor.cpp:259-268)
-    B_STEP(ensure_dev(h, h->bm_scratch, gipk_stereobm_scratch_bytes(w, hh, B, &bp)), "batch buffers");
     // launch context of the matcher: timing events on the stream it runs on, and (gip_batch_desc::matcher_stream) a stream of
     // its own fenced by a fork / join event pair
     BmLaunchCtx mctx;
@@ -1151,8 +1165,8 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         mctx.fork = h->match_fork;
         mctx.join = h->match_join;
     }
-    rc = gip_stereobm_impl((const uint8_t*)h->b_rect[0].p, (const uint8_t*)h->b_rect[1].p, rp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B,
-                           rplane, npx * 2, st, &mctx);
+    // both prefiltered planes are in the scratch already (null inputs)
+    rc = gip_stereobm_impl(nullptr, nullptr, pfp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, pfplane, npx * 2, st, &mctx);
     if (rc != GIP_OK) return propagate(h, rc, "stereobm");
     if (h->max_speckle_size > 0) {
         B_STEP(ensure_dev(h, h->spk_scratch, gipk_speckle_scratch_bytes(w, hh, B)), "batch buffers");

@@ -60,6 +60,10 @@ struct BmLaunchCtx;   // bm_common.h
 int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride, size_t cost_bstride, gip_stream stream,
                       bool skip_fill, const BmLaunchCtx* ctx);
-// gipk_stereobm with a launch context for the matcher (events around it, optional stream of its own)
+// gipk_stereobm with a launch context for the matcher (events around it, optional stream of its own).  left == right == nullptr
+// means the caller has already written the PREFILTERED planes into the scratch (gip_stereobm_planes tells where): the fused
+// rectify + XSOBEL front end of gip_batch_run does that.
 int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx);
+// prefiltered planes inside a gipk_stereobm scratch buffer: pitch, per-image plane size, and the two base pointers
+void gip_stereobm_planes(void* scratch, int w, int h, int batch, uint8_t** left_f, uint8_t** right_f, size_t* pitch, size_t* plane);

@@ -343,6 +343,103 @@ __global__ void __launch_bounds__(PN_TPB) k_prefilter_norm_sep(const uint8_t* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused rectify + XSOBEL
+// One pass raw -> prefiltered plane (and, when asked, the rectified plane as a by-product): the front end of "the remap+SAD kernel"
+// of the hot path (reference src/GPUStereoProcessor.cpp:236-250 rectifyImage, then :312-321 StereoBM's prefilter).  The rectified
+// image never makes the HBM round trip between k_remap_r4 and k_prefilter_xsobel_v4.
+//   * a workgroup = 4 waves stacked vertically over a strip of 62 output columns (lanes 1..62; lanes 0 and 63 rectify the strip's
+//     two halo columns); wave ty rectifies RX_ROWS consecutive rows, all of them in ONE gather step exactly like k_remap_r4 (table
+//     entries, then all taps in flight together; one table decode serves IM images of the batch) -- a gather kernel is bound by
+//     (waves / wave slots) x round trips, so the thread-level parallelism of the plain remap is kept (a first version that marched
+//     down the rows with carried state was 3.6x slower than the two kernels it replaced: 9 dependent gather steps per wave);
+//   * the horizontal difference r[x+1] - r[x-1] of a rectified row comes from the neighbour lanes (two lane shuffles); the vertical
+//     1-2-1 of the Sobel kernel needs the rows above and below: inside a thread's RX_ROWS rows they are its own registers, at the
+//     seam between two waves the first / last row of differences goes through LDS (one barrier).  The block's first and last rows
+//     are halo: 4 * RX_ROWS rectified rows give 4 * RX_ROWS - 2 output rows.
+// Bit-exact with k_remap_r4 followed by k_prefilter_xsobel (reflect-101 rows, columns 0 / w-1 and an odd last row = cap).
+#ifndef RX_ROWS_N
+#define RX_ROWS_N 5
+#endif
+constexpr int RX_ROWS = RX_ROWS_N;
+constexpr int RX_OUT = 4 * RX_ROWS - 2;     // output rows per workgroup
+constexpr int RX_COLS = 62;
+template <int IM>
+__global__ void __launch_bounds__(256) k_rectify_xsobel(const uint8_t* __restrict__ src, size_t sp, int sw, int sh, uint8_t* __restrict__ pf, size_t pfp,
+                                                        uint8_t* __restrict__ rect, size_t rp, int w, int h, const int16_t* __restrict__ map1,
+                                                        const uint16_t* __restrict__ map2, size_t sbs, size_t pfbs, size_t rbs, int cap)
+{
+    __shared__ short seam[2][4][IM][64];                    // [0]: first row of differences of wave ty, [1]: last row
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * RX_COLS - 1 + lane;
+    const int xc = clampi(x, 0, w - 1);
+    const bool out_lane = lane >= 1 && lane <= RX_COLS && x < w;
+    const int ya = blockIdx.y * RX_OUT, yb = min(ya + RX_OUT, h);   // output rows of the block
+    const int r0 = ya - 1 + ty * RX_ROWS;                            // first virtual row of this wave
+    const uint8_t* s0 = src + (size_t)blockIdx.z * IM * sbs;
+    uint8_t* pf0 = pf + (size_t)blockIdx.z * IM * pfbs;
+    uint8_t* rc0 = rect ? rect + (size_t)blockIdx.z * IM * rbs : nullptr;
+    int sx[RX_ROWS], sy[RX_ROWS], fr[RX_ROWS];
+#pragma unroll
+    for (int j = 0; j < RX_ROWS; j++) {
+        int r = r0 + j;                                     // virtual row: reflect-101 at the image edge
+        r = r < 0 ? (h > 1 ? 1 : 0) : (r > h - 1 ? (h > 1 ? 2 * (h - 1) - r : 0) : r);
+        r = clampi(r, 0, h - 1);                            // rows far past the image: no output needs them
+        const size_t o = (size_t)r * w + xc;
+        const short2 t = ((const short2*)map1)[o];
+        sx[j] = t.x;
+        sy[j] = t.y;
+        fr[j] = map2[o] & 1023;
+    }
+    int p[IM][RX_ROWS][4];
+#pragma unroll
+    for (int j = 0; j < RX_ROWS; j++) {
+        const bool bx0 = (unsigned)sx[j] < (unsigned)sw, bx1 = (unsigned)(sx[j] + 1) < (unsigned)sw;
+        const bool by0 = (unsigned)sy[j] < (unsigned)sh, by1 = (unsigned)(sy[j] + 1) < (unsigned)sh;
+        const ptrdiff_t off = (ptrdiff_t)sy[j] * (ptrdiff_t)sp + (ptrdiff_t)sx[j];
+#pragma unroll
+        for (int im = 0; im < IM; im++) {
+            const uint8_t* q = s0 + im * sbs + off;
+            p[im][j][0] = (bx0 && by0) ? q[0] : 0;
+            p[im][j][1] = (bx1 && by0) ? q[1] : 0;
+            p[im][j][2] = (bx0 && by1) ? q[sp] : 0;
+            p[im][j][3] = (bx1 && by1) ? q[sp + 1] : 0;
+        }
+    }
+    int hd[IM][RX_ROWS];
+#pragma unroll
+    for (int j = 0; j < RX_ROWS; j++) {
+        const int r = r0 + j;
+        const int ax = fr[j] & 31, ay = fr[j] >> 5, bx = 32 - ax, by = 32 - ay;
+#pragma unroll
+        for (int im = 0; im < IM; im++) {
+            const int top = p[im][j][0] * bx + p[im][j][1] * ax, bot = p[im][j][2] * bx + p[im][j][3] * ax;
+            const int v = (top * by + bot * ay + 512) >> 10;                // cv::remap fixed point, see k_remap_r4
+            if (rc0 && out_lane && r >= ya && r < yb) rc0[im * rbs + (size_t)r * rp + x] = (uint8_t)v;
+            hd[im][j] = __shfl_down(v, 1) - __shfl_up(v, 1);                // r[x+1] - r[x-1]
+        }
+    }
+#pragma unroll
+    for (int im = 0; im < IM; im++) {
+        seam[0][ty][im][lane] = (short)hd[im][0];
+        seam[1][ty][im][lane] = (short)hd[im][RX_ROWS - 1];
+    }
+    __syncthreads();
+    const bool odd_last = (h & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < RX_ROWS; j++) {
+        const int y = r0 + j;
+        if (y < ya || y >= yb || !out_lane) continue;       // the block's halo rows, rows past the image, halo lanes
+#pragma unroll
+        for (int im = 0; im < IM; im++) {
+            const int up = j > 0 ? hd[im][j - 1] : (int)seam[1][ty > 0 ? ty - 1 : 0][im][lane];
+            const int dn = j < RX_ROWS - 1 ? hd[im][j + 1] : (int)seam[0][ty < 3 ? ty + 1 : 3][im][lane];
+            const int acc = up + 2 * hd[im][j] + dn;
+            const int o = (x == 0 || x == w - 1 || (odd_last && y == h - 1)) ? cap : clampi(acc, -cap, cap) + cap;
+            pf0[im * pfbs + (size_t)y * pfp + x] = (uint8_t)o;
+        }
+    }
+}
+
 inline dim3 grid2d(int w, int h, int batch) { return dim3(gip_div_up(w, TPB), h, batch); }
 
 }  // namespace
@@ -458,6 +555,27 @@ int gipk_prefilter(const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t ds
     } else {
         return GIP_ERR_INVALID_ARG;
     }
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
+int gipk_rectify_xsobel(const uint8_t* src, size_t src_pitch, int sw, int sh, uint8_t* prefiltered, size_t pf_pitch, uint8_t* rectified, size_t rect_pitch,
+                        int w, int h, const int16_t* map1, const uint16_t* map2, int prefilter_cap, int batch, size_t sbs, size_t pf_bs, size_t rect_bs,
+                        gip_stream stream)
+{
+    GIPK_ARGCHECK(src && prefiltered && map1 && map2 && w > 0 && h > 0 && sw > 0 && sh > 0 && batch > 0 && prefilter_cap >= 1 && prefilter_cap <= 63);
+    GIPK_ARGCHECK(((uintptr_t)map1 & 3) == 0 && ((uintptr_t)map2 & 1) == 0);
+#ifndef RX_IM
+#define RX_IM 2    /* measured (tools/fe_ab.py): 2 images x 5 rows per thread 113 us, 4 x 5: 149 us, 1 x 5: 125 us per 64 images of 1242x375 */
+#endif
+    const bool multi = batch % RX_IM == 0 && RX_IM > 1;
+    const dim3 grid(gip_div_up(w, RX_COLS), gip_div_up(h, RX_OUT), multi ? batch / RX_IM : batch), block(64, 4);
+    if (multi)
+        hipLaunchKernelGGL((k_rectify_xsobel<RX_IM>), grid, block, 0, (hipStream_t)stream, src, src_pitch, sw, sh, prefiltered, pf_pitch, rectified, rect_pitch, w, h, map1, map2,
+                           sbs, pf_bs, rect_bs, prefilter_cap);
+    else
+        hipLaunchKernelGGL((k_rectify_xsobel<1>), grid, block, 0, (hipStream_t)stream, src, src_pitch, sw, sh, prefiltered, pf_pitch, rectified, rect_pitch, w, h, map1, map2,
+                           sbs, pf_bs, rect_bs, prefilter_cap);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }

@@ -834,10 +834,21 @@ int gipk_stereobm(const uint8_t* left, const uint8_t* right, size_t pitch, int w
 
 }  // extern "C"
 
+void gip_stereobm_planes(void* scratch, int w, int h, int batch, uint8_t** left_f, uint8_t** right_f, size_t* pitch, size_t* plane)
+{
+    const size_t pp = bm_plane_pitch(w);
+    uint8_t* base = (uint8_t*)gip_align_up((size_t)(uintptr_t)scratch, 256);
+    *left_f = base;
+    *right_f = base + pp * h * batch;
+    *pitch = pp;
+    *plane = pp * h;
+}
+
 int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx)
 {
-    GIPK_ARGCHECK(left && right && disp && scratch && p && w > 0 && h > 0 && batch > 0);
+    const bool prefiltered = !left && !right;
+    GIPK_ARGCHECK((prefiltered || (left && right)) && disp && scratch && p && w > 0 && h > 0 && batch > 0);
     int rc = gip_validate_bm_params(p, w, h);
     if (rc != GIP_OK) return rc;
     if (scratch_bytes < gipk_stereobm_scratch_bytes(w, h, batch, p)) return GIP_ERR_INVALID_ARG;
@@ -847,10 +858,12 @@ int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     uint8_t* rf = lf + plane * batch;
     int32_t* cost = (int32_t*)gip_align_up((size_t)(uintptr_t)(rf + plane * batch), 256);
     void* spk = (void*)gip_align_up((size_t)(uintptr_t)((uint8_t*)cost + (size_t)w * h * batch * 4), 256);
-    rc = gipk_prefilter(left, pitch, lf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
-    if (rc != GIP_OK) return rc;
-    rc = gipk_prefilter(right, pitch, rf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
-    if (rc != GIP_OK) return rc;
+    if (!prefiltered) {
+        rc = gipk_prefilter(left, pitch, lf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
+        if (rc != GIP_OK) return rc;
+        rc = gipk_prefilter(right, pitch, rf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
+        if (rc != GIP_OK) return rc;
+    }
     const bool lr = p->disp12_max_diff >= 0;
     rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true, ctx);
     if (rc != GIP_OK) return rc;

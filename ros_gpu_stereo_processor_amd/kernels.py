@@ -97,6 +97,21 @@ def prefilter(src, prefilter_type, prefilter_size, prefilter_cap):
     return dst if src.dim() == 3 else dst[0]
 
 
+def rectify_xsobel(src, map1, map2, prefilter_cap, want_rect=True):
+    """Fused remap + XSOBEL: returns (prefiltered, rectified or None).  src: (H,W) or (B,H,W) uint8; maps as for remap()."""
+    L = capi.lib()
+    s, B = _b(src, 2)
+    H, W = map1.shape[0], map1.shape[1]
+    SH, SW = s.shape[1], s.shape[2]
+    pf = torch.empty((B, H, W), dtype=torch.uint8, device=s.device)
+    rect = torch.empty((B, H, W), dtype=torch.uint8, device=s.device) if want_rect else None
+    _ck(L.gipk_rectify_xsobel(s.data_ptr(), SW, SW, SH, pf.data_ptr(), W, rect.data_ptr() if want_rect else None, W, W, H, map1.data_ptr(), map2.data_ptr(),
+                              prefilter_cap, B, SH * SW, H * W, H * W, _stream()))
+    if src.dim() == 2:
+        return pf[0], (rect[0] if want_rect else None)
+    return pf, rect
+
+
 def bm_match(left_f, right_f, params, want_cost=True):
     L = capi.lib()
     l, B = _b(left_f, 2)

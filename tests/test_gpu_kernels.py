@@ -119,6 +119,34 @@ def test_prefilter_norm_wide_windows(gpu, oracle):
             assert np.array_equal(_n(K.prefilter(_t(img, gpu), capi.PREFILTER_NORMALIZED_RESPONSE, ws, 31)), oracle.prefilter_norm(img, ws, 31)), (shape, ws)
 
 
+@pytest.mark.parametrize("shape", [(480, 752), (33, 47), (2, 9), (65, 62), (34, 125), (97, 187)])
+def test_fused_rectify_xsobel_bit_exact(gpu, oracle, calib, shape):
+    """The one-pass front end (raw -> prefiltered plane, rectified plane as a by-product) equals remap followed by XSOBEL: strips
+    of 62 columns, blocks of 18 rows, odd heights (last row = cap), batches of 4 (shared table decode) and of 3."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    h, w = shape
+    rng = np.random.default_rng(31 + h)
+    if shape == (480, 752):
+        c = calib["left"]
+        m1, m2 = oracle.init_undistort_rectify_map(c["K"], c["D"], c["R"], c["P"], w, h)
+    else:
+        # arbitrary tables incl. taps outside the source
+        yy, xx = np.mgrid[0:h, 0:w]
+        m1 = np.stack([xx + rng.integers(-3, 4, (h, w)), yy + rng.integers(-3, 4, (h, w))], -1).astype(np.int16)
+        m2 = rng.integers(0, 1024, (h, w)).astype(np.uint16)
+    for batch, cap in ((4, 31), (3, 63), (1, 5)):
+        raw = rng.integers(0, 256, (batch, h, w), dtype=np.uint8)
+        pf, rect = K.rectify_xsobel(_t(raw, gpu), _t(m1, gpu), _t(m2.view(np.int16), gpu), cap)
+        pf2, none = K.rectify_xsobel(_t(raw, gpu), _t(m1, gpu), _t(m2.view(np.int16), gpu), cap, want_rect=False)
+        assert none is None
+        for b in range(batch):
+            er = oracle.remap(raw[b], m1, m2)
+            assert np.array_equal(_n(rect[b]), er), (shape, batch, b)
+            ep = oracle.prefilter_xsobel(er, cap)
+            assert np.array_equal(_n(pf[b]), ep), (shape, batch, b)
+            assert np.array_equal(_n(pf2[b]), ep)
+
+
 # ---------------------------------------------------------------- block matcher
 def _prefiltered_pair(oracle, w, h, ndisp, seed):
     l, r, _ = synth.rectified_pair(w, h, min(ndisp, max(16, w // 3)), seed)

@@ -206,3 +206,33 @@ def test_rowsplit_equals_full_frame(gpu, shape, nd, block, world):
     split = RS.split_stereobm_simulated(lt, rt, p, world, block)
     assert torch.equal(full, split)
     assert (full != -16).float().mean() > 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prefilter_type", [1, 0])
+def test_batch_pipeline_fused_front_end_equals_two_pass(gpu, prefilter_type):
+    """gip_batch_run with the one-pass rectify + XSOBEL front end (gip_batch_desc::fused_front_end) and with the default two passes give the
+    same disparity, float disparity and cloud bytes (the cloud's colour comes from the rectified plane the fused pass writes as a
+    by-product); with the NORMALIZED_RESPONSE prefilter both runs take the two-pass form."""
+    import torch
+    from ros_gpu_stereo_processor_amd import capi, synth
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+    w, h, nd, B = 500, 131, 48, 4
+    calib = synth.scaled_calibration(w, h)
+    kw = dict(prefilter_type=prefilter_type, prefilter_size=9, prefilter_cap=31, block_size=11, min_disparity=0, num_disparities=nd, texture_threshold=10,
+              uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    raws = [synth.raw_pair(w, h, nd, seed=90 + i, calib=calib)[:2] for i in range(B)]
+    L = torch.from_numpy(np.stack([r[0] for r in raws])).to(gpu)
+    R = torch.from_numpy(np.stack([r[1] for r in raws])).to(gpu)
+    outs = []
+    for fused in (True, False):
+        pipe = BatchPipeline(w, h, calib, capi.BMParams(**kw), B, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 0, 60, 2.0, fused_front_end=fused)
+        pipe.install_maps(pipe.host_maps_to_device())
+        pipe.run(L, R)
+        torch.cuda.synchronize()
+        outs.append((pipe.disparity.cpu().numpy().copy(), pipe.disparity_f32.cpu().numpy().copy(), pipe.pointcloud.cpu().numpy().copy()))
+        pipe.close()
+    assert (outs[0][0] != -16).mean() > 0.2
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
