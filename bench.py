@@ -172,6 +172,53 @@ def single_pair_latency(lraw, rraw, calib, params, device, iters=30):
             "what": "gip_process_pair (imageCb schedule: upload L/R, mono, rectify L/R + colour L, StereoBM, speckle, reproject) for one %dx%d pair, host wall time incl. sync" % (W, H)}
 
 
+PCIE_GBS = 63.0  # /opt/skills/guides/MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec, per direction)
+
+
+def e2e_streaming(lraw, rraw, calib, params, device, budget_s=1.5):
+    """End-to-end pairs/s through the streaming C-ABI (gip_streamer_*): every pair starts as two raw images in pageable host memory
+    and ends as delivered outputs in pinned host memory -- pinned ring, H2D / compute / D2H on three HIP streams, 3 batches in flight,
+    hipLaunchHostFunc delivery.  Each record names its PCIe bound.  Not part of `value`."""
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd import processor as P
+    from ros_gpu_stereo_processor_amd.streamer import Streamer
+    px = W * H
+    cn = 3 if ENCODING in ("bgr8", "rgb8") else 1
+    proc = P.GpuStereoProcessor(device)
+    proc.initStereoModel(P.camera_info(W, H, **calib["left"]), P.camera_info(W, H, **calib["right"]))
+    proc.setParams(params)
+    proc.setMaxSpeckleSize(SPECKLE_SIZE)
+    proc.setMaxSpeckleDiff(SPECKLE_DIFF)
+    out = []
+    nsrc = len(lraw)
+    for name, outputs, out_bytes in (("raw H2D + f32 disparity D2H", capi.TOPIC_DISPARITY, 4 * px),
+                                     ("raw H2D + f32 disparity + 32-B PointCloud2 D2H", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 36 * px)):
+        for fpb in (1, 16):
+            st = Streamer(proc, W, H, ENCODING, outputs, depth=3, frames_per_batch=fpb)
+            for i in range(3 * fpb):          # warm-up: every ring slot used once
+                st.submit(lraw[i % nsrc], rraw[i % nsrc])
+            st.flush()
+            n, t0 = 0, time.perf_counter()
+            while True:
+                for i in range(fpb):
+                    st.submit(lraw[(n + i) % nsrc], rraw[(n + i) % nsrc])
+                n += fpb
+                if time.perf_counter() - t0 > budget_s / 4:
+                    break
+            st.flush()
+            dt = time.perf_counter() - t0
+            assert st.delivered() == n + 3 * fpb
+            st.close()
+            in_bytes = 2 * px * cn
+            bound = PCIE_GBS * 1e9 / max(in_bytes, out_bytes)     # full duplex: the larger direction binds
+            out.append({"what": name, "pairs_per_batch": fpb, "batches_in_flight": 3, "pairs": n, "pairs_per_s": round(n / dt, 1), "ms_per_pair": round(1e3 * dt / n, 4),
+                        "h2d_bytes_per_pair": in_bytes, "d2h_bytes_per_pair": out_bytes, "pcie_bound_pairs_per_s": round(bound, 1),
+                        "frac_of_pcie_bound": round(n / dt / bound, 4)})
+    proc.close()
+    return {"api": "gip_streamer_open/submit/flush (pinned ring, 3 HIP streams, hipLaunchHostFunc delivery)", "pcie_gbs_spec_per_direction": PCIE_GBS,
+            "host_input": "pageable numpy arrays, copied into the pinned ring by the submitting thread", "records": out}
+
+
 def main():
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-chain-only":   # child of cpu_baseline(): host cores only, no GPU, no torch
         n, dt, threads = _cpu_chain_timed(sys.argv[2], budget_s=float(sys.argv[3]) if len(sys.argv) > 3 else 6.0, max_pairs=100000)
@@ -194,6 +241,7 @@ def main():
                     "(bit-identical; measured slower on MI355X, DESIGN.md 3.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end streaming measurement (host memory in, host memory out)")
     args = ap.parse_args()
     global W, H, NDISP, BLOCK, ENCODING
     wl = WORKLOADS[args.workload]
@@ -320,6 +368,8 @@ def main():
         }
         if world == 1 and not args.no_latency:
             out["latency"] = single_pair_latency(lraw[0], rraw[0], calib, params, local_rank)
+        if world == 1 and not args.no_e2e:
+            out["e2e"] = e2e_streaming(lraw, rraw, calib, params, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

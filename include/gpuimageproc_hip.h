@@ -168,6 +168,8 @@ typedef void *gip_stream; /* hipStream_t */
 int gip_create(int device, gip_handle *out);
 int gip_destroy(gip_handle h);
 const char *gip_last_error(gip_handle h);
+/* the HIP device the handle was created on */
+int gip_device(gip_handle h);
 const char *gip_status_string(int status);
 int gip_device_count(void);
 
@@ -248,6 +250,45 @@ int gip_set_params(gip_handle h, const gip_bm_params *p);
  * Synchronous like the reference (ends with waitForAllStreams). */
 int gip_process_pair(gip_handle h, const void *left_raw, const void *right_raw, int rows, int cols, size_t step, int type,
                      const char *encoding, uint32_t connected_topics);
+
+/* ================================================================== streaming pipeline (gip_streamer_*)
+ * The host link of the nodelet: the reference uploads both raws per frame (src/StereoProcessor.cpp:179-180), runs the chain,
+ * hands every output to a stream host callback (src/GpuSenderIfc.cpp:13-26) and then BLOCKS on waitForAllStreams()
+ * (src/StereoProcessor.cpp:284), i.e. one frame in flight.  The streamer keeps `depth` batches in flight instead: a ring of
+ * pinned input / output buffers, hipMemcpyAsync H2D on a copy-in stream, the chain (gip_batch_run) on a compute stream, D2H on a
+ * copy-out stream, delivery through hipLaunchHostFunc on the copy-out stream.  Upload of frame i+1, compute of frame i and
+ * download of frame i-1 overlap; gip_streamer_submit blocks only when every ring slot is still in flight (back-pressure).
+ * The processor handle must have its model and parameters set; it must not be used for anything else while a streamer is open. */
+typedef struct gip_streamer_s *gip_streamer;
+typedef struct gip_streamer_config {
+    int32_t width, height;
+    int32_t encoding;        /* as gip_batch_desc::encoding */
+    uint32_t outputs;        /* GIP_TOPIC_DISPARITY (float disparity, 4 B/px) and/or GIP_TOPIC_POINTCLOUD (32 B/px) delivered */
+    int32_t want_disparity16;/* also deliver the int16 x16 map (2 B/px) */
+    int32_t depth;           /* ring slots = batches in flight (>= 2; 0 -> 3) */
+    int32_t frames_per_batch;/* stereo pairs per compute launch (>= 1; 0 -> 1).  1 = lowest latency; larger batches fill the GPU
+                              * (a single 1242x375 pair occupies a tenth of it) at the price of batch latency */
+} gip_streamer_config;
+typedef struct gip_streamer_result {
+    uint64_t seq;                 /* submission index of this pair (0, 1, ...) */
+    gip_header header;            /* as submitted */
+    int32_t width, height;
+    const int16_t *disparity16;   /* pinned host memory, valid until the callback returns; NULL when not requested */
+    const float *disparity_f32;
+    const uint8_t *pointcloud;    /* height * width * 32 bytes, PointCloud2 body */
+} gip_streamer_result;
+/* runs on a HIP runtime thread, once per pair, in submission order */
+typedef void (*gip_streamer_cb)(const gip_streamer_result *result, void *user);
+
+int gip_streamer_open(gip_handle h, const gip_streamer_config *cfg, gip_streamer_cb cb, void *user, gip_streamer *out);
+/* copies both raw images (rows `step` bytes apart; 0 = tight) into the ring and returns; a partial batch is launched by flush */
+int gip_streamer_submit(gip_streamer s, const void *left_raw, const void *right_raw, size_t step, const gip_header *header);
+/* launch a partially filled batch and wait until every submitted pair has been delivered */
+int gip_streamer_flush(gip_streamer s);
+/* pairs delivered so far (callback returned) */
+uint64_t gip_streamer_delivered(gip_streamer s);
+int gip_streamer_close(gip_streamer s);
+const char *gip_streamer_last_error(gip_streamer s);
 
 /* ================================================================== stateless device kernels (gipk_*)
  * All pointers are DEVICE pointers; pitches in BYTES unless suffixed _elems; `batch` images are laid out

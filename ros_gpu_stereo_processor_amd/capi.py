@@ -83,6 +83,17 @@ class BatchDesc(C.Structure):
                 ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p), ("fused_front_end", C.c_int32)]
 
 
+class StreamerConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32), ("want_disparity16", C.c_int32),
+                ("depth", C.c_int32), ("frames_per_batch", C.c_int32)]
+
+
+class StreamerResult(C.Structure):
+    _fields_ = [("seq", C.c_uint64), ("header", Header), ("width", C.c_int32), ("height", C.c_int32), ("disparity16", C.c_void_p),
+                ("disparity_f32", C.c_void_p), ("pointcloud", C.c_void_p)]
+
+
+STREAMER_CB = C.CFUNCTYPE(None, C.POINTER(StreamerResult), C.c_void_p)
 IMAGE_CB = C.CFUNCTYPE(None, C.POINTER(ImageMsg), C.c_void_p)
 DISPARITY_CB = C.CFUNCTYPE(None, C.POINTER(DisparityMsg), C.c_void_p)
 POINTCLOUD2_CB = C.CFUNCTYPE(None, C.POINTER(PointCloud2Msg), C.c_void_p)
@@ -94,6 +105,7 @@ PROTOTYPES = {
     "gip_create": (_i, [_i, C.POINTER(_vp)]),
     "gip_destroy": (_i, [_vp]),
     "gip_last_error": (C.c_char_p, [_vp]),
+    "gip_device": (_i, [_vp]),
     "gip_status_string": (C.c_char_p, [_i]),
     "gip_device_count": (_i, []),
     "gip_init_stereo_model": (_i, [_vp, C.POINTER(CameraInfo), C.POINTER(CameraInfo)]),
@@ -170,6 +182,12 @@ PROTOTYPES = {
     "gip_batch_run": (_i, [_vp, C.POINTER(BatchDesc), _vp]),
     "gip_batch_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gip_batch_timing_reset": (_i, [_vp]),
+    "gip_streamer_open": (_i, [_vp, C.POINTER(StreamerConfig), STREAMER_CB, _vp, C.POINTER(_vp)]),
+    "gip_streamer_submit": (_i, [_vp, _vp, _vp, _sz, C.POINTER(Header)]),
+    "gip_streamer_flush": (_i, [_vp]),
+    "gip_streamer_delivered": (C.c_uint64, [_vp]),
+    "gip_streamer_close": (_i, [_vp]),
+    "gip_streamer_last_error": (C.c_char_p, [_vp]),
     "gip_batch_timing_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
 }
 

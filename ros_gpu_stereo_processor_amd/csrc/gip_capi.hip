@@ -393,6 +393,7 @@ int gip_destroy(gip_handle h)
 }
 
 const char* gip_last_error(gip_handle h) { return h ? h->err.c_str() : "null handle"; }
+int gip_device(gip_handle h) { return h ? h->device : -1; }
 
 // ------------------------------------------------------------------------------------------------ model
 int gip_init_stereo_model(gip_handle h, const gip_camera_info* left, const gip_camera_info* right)

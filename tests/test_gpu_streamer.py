@@ -1,0 +1,87 @@
+"""The streaming C-ABI (gip_streamer_*): pinned ring, three HIP streams, host-callback delivery.  Streamed outputs must equal what
+the synchronous per-frame schedule (gip_process_pair = StereoProcessor::imageCb, reference src/StereoProcessor.cpp:157-298) leaves in
+the slots for the same pair, in submission order, for every ring depth / batch size incl. a partial last batch."""
+import numpy as np
+import pytest
+
+from ros_gpu_stereo_processor_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _processor(w, h, nd, block):
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd import processor as P
+    calib = synth.scaled_calibration(w, h)
+    proc = P.GpuStereoProcessor(0)
+    proc.initStereoModel(P.camera_info(w, h, **calib["left"]), P.camera_info(w, h, **calib["right"]))
+    proc.setParams(capi.BMParams(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=block, min_disparity=0, num_disparities=nd,
+                                 texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0))
+    proc.setMaxSpeckleSize(60)
+    proc.setMaxSpeckleDiff(2.0)
+    return proc, calib
+
+
+@pytest.mark.parametrize("depth,fpb,nframes", [(3, 1, 7), (2, 2, 5), (4, 3, 10)])
+def test_streamed_outputs_equal_process_pair(gpu, depth, fpb, nframes):
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd import processor as P
+    from ros_gpu_stereo_processor_amd.streamer import Streamer
+    w, h, nd = 400, 120, 48
+    proc, calib = _processor(w, h, nd, 9)
+    frames = [synth.raw_pair(w, h, nd, seed=200 + i, calib=calib)[:2] for i in range(nframes)]
+    # reference results: the synchronous schedule, one pair at a time
+    exp = []
+    for l, r in frames:
+        proc.processPair(l, r, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD)
+        d16 = proc.downloadMat(P.L_DISPARITY)
+        f32 = proc.downloadMat(P.L_DISPARITY_32F)
+        sid = proc.enqueueSendPoints(P.L_POINTS2, P.L_RECT_COLOR)
+        proc.waitForAllStreams()
+        exp.append((d16.copy(), f32.copy(), proc.pointCloudMessage(sid)["data"].copy()))
+        proc.cleanSenders()
+    assert (exp[0][0] != -16).mean() > 0.2
+    got = {}
+    order = []
+
+    def on_result(seq, header, d16, f32, cloud):
+        order.append(seq)
+        got[seq] = (header.seq, d16, f32, cloud)
+    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, want_disparity16=True, depth=depth, frames_per_batch=fpb, on_result=on_result)
+    for i, (l, r) in enumerate(frames):
+        hdr = capi.Header(seq=1000 + i, stamp_sec=i, stamp_nsec=7, frame_id=b"cam")
+        st.submit(l, r, hdr)
+    st.flush()
+    assert st.delivered() == nframes
+    assert order == list(range(nframes))                       # delivery in submission order
+    for i in range(nframes):
+        hseq, d16, f32, cloud = got[i]
+        assert hseq == 1000 + i
+        assert np.array_equal(d16, exp[i][0]), i
+        assert np.array_equal(f32, exp[i][1]), i
+        assert np.array_equal(cloud.view(np.uint8), exp[i][2].view(np.uint8)), i
+    # the ring keeps working after a flush
+    st.submit(*frames[0])
+    st.flush()
+    assert st.delivered() == nframes + 1 and np.array_equal(got[nframes][1], exp[0][0])
+    st.close()
+    proc.close()
+
+
+def test_streamer_counts_without_callback_and_rejects_bad_config(gpu):
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.streamer import Streamer
+    w, h, nd = 320, 96, 32
+    proc, calib = _processor(w, h, nd, 7)
+    l, r = synth.raw_pair(w, h, nd, seed=3, calib=calib)[:2]
+    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY, depth=3, frames_per_batch=4)
+    for _ in range(9):
+        st.submit(l, r)
+    st.flush()
+    assert st.delivered() == 9
+    st.close()
+    with pytest.raises(capi.GipError):
+        Streamer(proc, w + 2, h, "mono8", capi.TOPIC_DISPARITY)      # size differs from the calibration
+    with pytest.raises(capi.GipError):
+        Streamer(proc, w, h, "mono8", 0)                              # nothing to deliver
+    proc.close()

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; shift
 rm -rf /tmp/ks_run
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_run -o r -- python3 $R/bench.py --no-cpu-baseline --no-latency "$@" > ${OUT%.csv}.bench.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_run -o r -- python3 $R/bench.py --no-cpu-baseline --no-latency --no-e2e "$@" > ${OUT%.csv}.bench.txt 2>&1
 cp $(find /tmp/ks_run -name "*kernel_stats.csv" | head -1) $OUT
 python3 - "$OUT" <<'PY'
 import csv,sys
