@@ -102,12 +102,18 @@ typedef struct gip_bm_params {
 
 /* sensor_msgs/CameraInfo fields the model needs (GPUStereoProcessor.cpp:41-53) */
 typedef struct gip_camera_info {
-    int32_t width, height;
+    int32_t width, height;   /* FULL resolution the camera was calibrated at (sensor_msgs/CameraInfo width / height) */
     double K[9];
     double D[8];
     int32_t nD;
     double R[9];
     double P[12];
+    /* sensor_msgs/CameraInfo binning and region of interest, applied as image_geometry::PinholeCameraModel::fromCameraInfo /
+     * initRectificationMaps do: the images the processor sees are the ROI of the full frame, decimated by the binning factors;
+     * K and P are shifted by the ROI offset and scaled by 1 / binning, the rectification tables are the ROI window of the tables of
+     * the binned full frame with the ROI origin subtracted.  All zero (the default) = no binning, full-frame ROI. */
+    uint32_t binning_x, binning_y;
+    uint32_t roi_x_offset, roi_y_offset, roi_height, roi_width;
 } gip_camera_info;
 
 /* ------------------------------------------------------------------ message PODs (the senders' payloads) */

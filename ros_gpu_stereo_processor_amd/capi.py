@@ -49,7 +49,8 @@ class BMParams(C.Structure):
 
 class CameraInfo(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("K", C.c_double * 9), ("D", C.c_double * 8), ("nD", C.c_int32),
-                ("R", C.c_double * 9), ("P", C.c_double * 12)]
+                ("R", C.c_double * 9), ("P", C.c_double * 12), ("binning_x", C.c_uint32), ("binning_y", C.c_uint32), ("roi_x_offset", C.c_uint32),
+                ("roi_y_offset", C.c_uint32), ("roi_height", C.c_uint32), ("roi_width", C.c_uint32)]
 
 
 class Header(C.Structure):

@@ -51,11 +51,13 @@ struct Slot {
     hipEvent_t read = nullptr;    // recorded after the last read from a foreign stream
     hipStream_t writer = nullptr;
     bool has_reader = false;
-    // pinned staging for uploadMat
-    void* stage = nullptr;
-    size_t stage_cap = 0;
-    hipEvent_t stage_done = nullptr;
-    bool stage_busy = false;
+    // pinned staging for uploadMat: two buffers used alternately, so that staging frame i+1 (a host memcpy) does not wait for the
+    // H2D copy of frame i
+    void* stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    int stage_next = 0;
 };
 
 enum SenderKind { SEND_IMAGE, SEND_DISPARITY, SEND_POINTS };
@@ -169,7 +171,8 @@ int slot_create(gip_handle h, int id, int rows, int cols, int type, Slot** out)
     if (!s.ready) {
         H_HIP(h, hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
         H_HIP(h, hipEventCreateWithFlags(&s.read, hipEventDisableTiming));
-        H_HIP(h, hipEventCreateWithFlags(&s.stage_done, hipEventDisableTiming));
+        H_HIP(h, hipEventCreateWithFlags(&s.stage_done[0], hipEventDisableTiming));
+        H_HIP(h, hipEventCreateWithFlags(&s.stage_done[1], hipEventDisableTiming));
     }
     if (s.cap < need) {
         if (s.d) {
@@ -368,10 +371,12 @@ int gip_destroy(gip_handle h)
     for (auto& kv : h->slots) {
         Slot& s = kv.second;
         if (s.d) hipFree(s.d);
-        if (s.stage) hipHostFree(s.stage);
-        if (s.ready) hipEventDestroy(s.ready);
-        if (s.read) hipEventDestroy(s.read);
-        if (s.stage_done) hipEventDestroy(s.stage_done);
+        for (int k = 0; k < 2; k++) {
+            if (s.stage[k]) (void)hipHostFree(s.stage[k]);
+            if (s.stage_done[k]) (void)hipEventDestroy(s.stage_done[k]);
+        }
+        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (s.read) (void)hipEventDestroy(s.read);
     }
     for (auto& pp : h->pinned_pool) (void)hipHostFree(pp.first);
     if (h->maps_owned)
@@ -437,6 +442,8 @@ int gip_build_rectify_maps(const gip_camera_info* info, int16_t* map1, uint16_t*
 {
     if (!info || !map1 || !map2 || info->width <= 0 || info->height <= 0 || info->width > 32767 || info->height > 32767 || info->nD < 0 || info->nD > 8)
         return GIP_ERR_INVALID_ARG;
+    gip_camera_info eff;
+    if (!gip_effective_camera(*info, eff)) return GIP_ERR_INVALID_ARG;   // the tables have eff.width x eff.height entries
     std::vector<int16_t> m1;
     std::vector<uint16_t> m2;
     gip_build_rectify_map(*info, m1, m2);
@@ -494,22 +501,26 @@ int gip_upload_mat(gip_handle h, int slot, const void* data, int rows, int cols,
     hipStream_t st = stream_of(h, slot);
     // pinned staging: the caller's buffer is free again when this returns (as with the reference's CPU copy)
     const size_t bytes = row_bytes * rows;
-    if (s->stage_busy) {
-        H_HIP(h, hipEventSynchronize(s->stage_done));
-        s->stage_busy = false;
+    const int k = s->stage_next;            // the buffer whose H2D copy was issued two uploads ago
+    s->stage_next ^= 1;
+    if (s->stage_busy[k]) {
+        H_HIP(h, hipEventSynchronize(s->stage_done[k]));
+        s->stage_busy[k] = false;
     }
-    if (s->stage_cap < bytes) {
-        if (s->stage) H_HIP(h, hipHostFree(s->stage));
-        s->stage = nullptr;
-        H_HIP(h, hipHostMalloc(&s->stage, bytes, hipHostMallocDefault));
-        s->stage_cap = bytes;
+    if (s->stage_cap[k] < bytes) {
+        if (s->stage[k]) H_HIP(h, hipHostFree(s->stage[k]));
+        s->stage[k] = nullptr;
+        H_HIP(h, hipHostMalloc(&s->stage[k], bytes, hipHostMallocDefault));
+        s->stage_cap[k] = bytes;
     }
-    for (int y = 0; y < rows; y++) std::memcpy((uint8_t*)s->stage + (size_t)y * row_bytes, (const uint8_t*)data + (size_t)y * step, row_bytes);
+    if (step == row_bytes) std::memcpy(s->stage[k], data, bytes);
+    else
+        for (int y = 0; y < rows; y++) std::memcpy((uint8_t*)s->stage[k] + (size_t)y * row_bytes, (const uint8_t*)data + (size_t)y * step, row_bytes);
     rc = begin_write(h, s, st);
     if (rc != GIP_OK) return rc;
-    H_HIP(h, hipMemcpyAsync(s->d, s->stage, bytes, hipMemcpyHostToDevice, st));   // s->pitch == row_bytes
-    H_HIP(h, hipEventRecord(s->stage_done, st));
-    s->stage_busy = true;
+    H_HIP(h, hipMemcpyAsync(s->d, s->stage[k], bytes, hipMemcpyHostToDevice, st));   // s->pitch == row_bytes
+    H_HIP(h, hipEventRecord(s->stage_done[k], st));
+    s->stage_busy[k] = true;
     rc = end_write(h, s, st);
     if (rc != GIP_OK) return rc;
     if (encoding && encoding[0]) {
@@ -995,22 +1006,91 @@ int gip_wait_for_all_streams(gip_handle h)
     return GIP_OK;
 }
 
-int gip_set_pre_filter_type(gip_handle h, int v) { H_CHECK(h); h->params.prefilter_type = v; return GIP_OK; }
+// Setters validate what can never be valid (the reference forwards to cv::StereoBM setters that accept anything and fails later
+// inside compute(); its configCb makes the window odd and the range a multiple of 16 first, reference src/StereoProcessor.cpp:309-311 --
+// StereoProcessor::configCb of include/gpuimageproc/StereoProcessor.hpp does the same before calling these).  A rejected value
+// leaves the parameter unchanged.
+#define GIP_SETTER(cond, text)                                   \
+    do {                                                         \
+        H_CHECK(h);                                              \
+        if (!(cond)) return fail(h, GIP_ERR_INVALID_ARG, text);  \
+    } while (0)
+int gip_set_pre_filter_type(gip_handle h, int v)
+{
+    GIP_SETTER(v == GIP_PREFILTER_NORMALIZED_RESPONSE || v == GIP_PREFILTER_XSOBEL, "setPreFilterType: 0 (NORMALIZED_RESPONSE) or 1 (XSOBEL)");
+    h->params.prefilter_type = v;
+    return GIP_OK;
+}
 int gip_set_refine_disparity(gip_handle h, int v) { H_CHECK(h); h->refine_disparity = v; return GIP_OK; }
-int gip_set_block_size(gip_handle h, int v) { H_CHECK(h); h->params.block_size = v; return GIP_OK; }
-int gip_set_num_disparities(gip_handle h, int v) { H_CHECK(h); h->params.num_disparities = v; return GIP_OK; }
-int gip_set_min_disparity(gip_handle h, int v) { H_CHECK(h); h->params.min_disparity = v; return GIP_OK; }
-int gip_set_texture_threshold(gip_handle h, int v) { H_CHECK(h); h->params.texture_threshold = v; return GIP_OK; }
-int gip_set_max_speckle_size(gip_handle h, int v) { H_CHECK(h); h->max_speckle_size = v; return GIP_OK; }
+int gip_set_block_size(gip_handle h, int v)
+{
+    GIP_SETTER(v >= 5 && v <= 255 && (v & 1), "setBlockSize: odd, 5..255 (cfg/GPU.cfg:16)");
+    h->params.block_size = v;
+    return GIP_OK;
+}
+int gip_set_num_disparities(gip_handle h, int v)
+{
+    GIP_SETTER(v > 0 && v % 16 == 0 && v <= 4096, "setNumDisparities: positive multiple of 16");
+    h->params.num_disparities = v;
+    return GIP_OK;
+}
+int gip_set_min_disparity(gip_handle h, int v)
+{
+    GIP_SETTER(v >= -2047 && v <= 2047, "setMinDisparity: |minDisparity| <= 2047 (x16 fixed point in int16)");
+    h->params.min_disparity = v;
+    return GIP_OK;
+}
+int gip_set_texture_threshold(gip_handle h, int v)
+{
+    GIP_SETTER(v >= 0, "setTextureThreshold: >= 0");
+    h->params.texture_threshold = v;
+    return GIP_OK;
+}
+int gip_set_max_speckle_size(gip_handle h, int v)
+{
+    GIP_SETTER(v >= 0, "setMaxSpeckleSize: >= 0 (0 disables the filter)");
+    h->max_speckle_size = v;
+    return GIP_OK;
+}
 int gip_get_max_speckle_size(gip_handle h) { return h ? h->max_speckle_size : 0; }
-int gip_set_max_speckle_diff(gip_handle h, double v) { H_CHECK(h); h->max_speckle_diff = v; return GIP_OK; }
+int gip_set_max_speckle_diff(gip_handle h, double v)
+{
+    GIP_SETTER(v >= 0.0 && v <= 2047.0, "setMaxSpeckleDiff: 0..2047 disparities");
+    h->max_speckle_diff = v;
+    return GIP_OK;
+}
 double gip_get_max_speckle_diff(gip_handle h) { return h ? h->max_speckle_diff : 0.0; }
-int gip_set_pre_filter_size(gip_handle h, int v) { H_CHECK(h); h->params.prefilter_size = v; return GIP_OK; }
-int gip_set_pre_filter_cap(gip_handle h, int v) { H_CHECK(h); h->params.prefilter_cap = v; return GIP_OK; }
-int gip_set_uniqueness_ratio(gip_handle h, int v) { H_CHECK(h); h->params.uniqueness_ratio = v; return GIP_OK; }
+int gip_set_pre_filter_size(gip_handle h, int v)
+{
+    GIP_SETTER(v >= 5 && v <= 255 && (v & 1), "setPreFilterSize: odd, 5..255");
+    h->params.prefilter_size = v;
+    return GIP_OK;
+}
+int gip_set_pre_filter_cap(gip_handle h, int v)
+{
+    GIP_SETTER(v >= 1 && v <= 63, "setPreFilterCap: 1..63");
+    h->params.prefilter_cap = v;
+    return GIP_OK;
+}
+int gip_set_uniqueness_ratio(gip_handle h, int v)
+{
+    GIP_SETTER(v >= 0, "setUniquenessRatio: >= 0");
+    h->params.uniqueness_ratio = v;
+    return GIP_OK;
+}
 int gip_set_disp12_max_diff(gip_handle h, int v) { H_CHECK(h); h->params.disp12_max_diff = v; return GIP_OK; }
+#undef GIP_SETTER
 int gip_get_params(gip_handle h, gip_bm_params* out) { H_CHECK(h); if (!out) return GIP_ERR_INVALID_ARG; *out = h->params; return GIP_OK; }
-int gip_set_params(gip_handle h, const gip_bm_params* p) { H_CHECK(h); if (!p) return GIP_ERR_INVALID_ARG; h->params = *p; return GIP_OK; }
+int gip_set_params(gip_handle h, const gip_bm_params* p)
+{
+    H_CHECK(h);
+    if (!p) return GIP_ERR_INVALID_ARG;
+    // the whole block at once: size-independent part of StereoBMImpl::compute's checks (the size-dependent one, block < min(w, h),
+    // stays in computeDisparity)
+    if (gip_validate_bm_params(p, 1 << 30, 1 << 30) != GIP_OK) return fail(h, GIP_ERR_INVALID_ARG, "setParams: invalid StereoBM parameter block");
+    h->params = *p;
+    return GIP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ imageCb schedule
 int gip_process_pair(gip_handle h, const void* left_raw, const void* right_raw, int rows, int cols, size_t step, int type, const char* encoding,

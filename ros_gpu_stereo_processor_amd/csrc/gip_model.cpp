@@ -55,7 +55,70 @@ inline int round_sat(double v)
 
 // cv::initUndistortRectifyMap(K, D, R, P, size, CV_16SC2): for every rectified pixel, project back through
 // inv(P[:,:3] * R), apply the plumb-bob / rational distortion, and store the source coordinate with 5 fractional bits.
+// image_geometry::PinholeCameraModel::fromCameraInfo: K, P of the images actually delivered
+bool gip_effective_camera(const gip_camera_info& full, gip_camera_info& eff)
+{
+    eff = full;
+    const int bx = full.binning_x ? (int)full.binning_x : 1, by = full.binning_y ? (int)full.binning_y : 1;
+    int rx = (int)full.roi_x_offset, ry = (int)full.roi_y_offset, rw = (int)full.roi_width, rh = (int)full.roi_height;
+    if (rx == 0 && ry == 0 && rw == 0 && rh == 0) { rw = full.width; rh = full.height; }   // all zero = full resolution
+    if (rw <= 0 || rh <= 0 || rx < 0 || ry < 0 || rx + rw > full.width || ry + rh > full.height) return false;
+    if (rx != 0 || ry != 0) {
+        eff.K[2] -= rx; eff.K[5] -= ry;
+        eff.P[2] -= rx; eff.P[6] -= ry;
+    }
+    if (bx > 1) {
+        const double sx = 1.0 / bx;
+        eff.K[0] *= sx; eff.K[2] *= sx;
+        eff.P[0] *= sx; eff.P[2] *= sx; eff.P[3] *= sx;
+    }
+    if (by > 1) {
+        const double sy = 1.0 / by;
+        eff.K[4] *= sy; eff.K[5] *= sy;
+        eff.P[5] *= sy; eff.P[6] *= sy; eff.P[7] *= sy;
+    }
+    eff.width = rw / bx;
+    eff.height = rh / by;
+    eff.binning_x = eff.binning_y = 0;
+    eff.roi_x_offset = eff.roi_y_offset = eff.roi_width = eff.roi_height = 0;
+    return eff.width > 0 && eff.height > 0;
+}
+
+static void build_full_map(const gip_camera_info& ci, std::vector<int16_t>& map1, std::vector<uint16_t>& map2);
+
+// image_geometry::PinholeCameraModel::initRectificationMaps: tables of the BINNED FULL frame (K, P scaled by 1 / binning, not
+// shifted), then the ROI window of them with the ROI origin subtracted from the integer coordinates
 void gip_build_rectify_map(const gip_camera_info& ci, std::vector<int16_t>& map1, std::vector<uint16_t>& map2)
+{
+    const int bx = ci.binning_x ? (int)ci.binning_x : 1, by = ci.binning_y ? (int)ci.binning_y : 1;
+    int rx = (int)ci.roi_x_offset, ry = (int)ci.roi_y_offset, rw = (int)ci.roi_width, rh = (int)ci.roi_height;
+    const bool full_roi = (rx == 0 && ry == 0 && rw == 0 && rh == 0) || (rx == 0 && ry == 0 && rw == ci.width && rh == ci.height);
+    if (bx == 1 && by == 1 && full_roi) { build_full_map(ci, map1, map2); return; }
+    gip_camera_info b = ci;
+    b.binning_x = b.binning_y = 0;
+    b.roi_x_offset = b.roi_y_offset = b.roi_width = b.roi_height = 0;
+    b.width = ci.width / bx;
+    b.height = ci.height / by;
+    const double sx = 1.0 / bx, sy = 1.0 / by;
+    if (bx > 1) { b.K[0] *= sx; b.K[2] *= sx; b.P[0] *= sx; b.P[2] *= sx; b.P[3] *= sx; }
+    if (by > 1) { b.K[4] *= sy; b.K[5] *= sy; b.P[5] *= sy; b.P[6] *= sy; b.P[7] *= sy; }
+    std::vector<int16_t> f1;
+    std::vector<uint16_t> f2;
+    build_full_map(b, f1, f2);
+    if (full_roi) { map1.swap(f1); map2.swap(f2); return; }
+    rx /= bx; ry /= by; rw /= bx; rh /= by;
+    map1.resize((size_t)rw * rh * 2);
+    map2.resize((size_t)rw * rh);
+    for (int y = 0; y < rh; y++)
+        for (int x = 0; x < rw; x++) {
+            const size_t o = (size_t)(y + ry) * b.width + (x + rx), d = (size_t)y * rw + x;
+            map1[2 * d] = (int16_t)(f1[2 * o] - rx);
+            map1[2 * d + 1] = (int16_t)(f1[2 * o + 1] - ry);
+            map2[d] = f2[o];
+        }
+}
+
+static void build_full_map(const gip_camera_info& ci, std::vector<int16_t>& map1, std::vector<uint16_t>& map2)
 {
     const int w = ci.width, h = ci.height, nD = ci.nD;
     const double* D = ci.D;
@@ -93,16 +156,20 @@ void gip_build_rectify_map(const gip_camera_info& ci, std::vector<int16_t>& map1
 
 int gip_model_init(GipStereoModel& m, const gip_camera_info& l, const gip_camera_info& r)
 {
-    if (l.width <= 0 || l.height <= 0 || l.width != r.width || l.height != r.height) return GIP_ERR_INVALID_ARG;
-    if (l.width > 32767 || l.height > 32767) return GIP_ERR_INVALID_ARG;
+    if (l.width <= 0 || l.height <= 0 || l.width > 32767 || l.height > 32767 || r.width <= 0 || r.height <= 0 || r.width > 32767 || r.height > 32767) return GIP_ERR_INVALID_ARG;
     if (l.nD < 0 || l.nD > 8 || r.nD < 0 || r.nD > 8) return GIP_ERR_INVALID_ARG;
     if (r.P[0] == 0.0 || l.P[0] == 0.0) return GIP_ERR_INVALID_ARG;
-    m.left.info = l;
-    m.right.info = r;
+    gip_camera_info le, re;
+    if (!gip_effective_camera(l, le) || !gip_effective_camera(r, re)) return GIP_ERR_INVALID_ARG;
+    if (le.width != re.width || le.height != re.height) return GIP_ERR_INVALID_ARG;   // both eyes must deliver images of one size
+    m.left.full = l;
+    m.right.full = r;
+    m.left.info = le;
+    m.right.info = re;
     GipPinhole* cams[2] = {&m.left, &m.right};
     for (GipPinhole* c : cams) {
         c->distorted = !(c->info.nD == 0 || c->info.D[0] == 0.0);
-        gip_build_rectify_map(c->info, c->map1, c->map2);
+        gip_build_rectify_map(c->full, c->map1, c->map2);
     }
     // image_geometry::StereoCameraModel::updateQ
     const double Tx = -m.baseline();
@@ -217,6 +284,7 @@ static int parse_calibration_ini(const std::string& path, const std::string& tex
 // camera_calibration_parsers::readCalibration picks the format by extension (.ini, .yml/.yaml)
 int gip_parse_calibration_yaml(const std::string& path, gip_camera_info& out, std::string& camera_name, std::string& err)
 {
+    out = gip_camera_info{};   // calibration files carry no binning / ROI: full frame
     std::ifstream f(path);
     if (!f) { err = "cannot open calibration file " + path; return GIP_ERR_IO; }
     std::stringstream buf;

@@ -24,9 +24,12 @@ def _type_of(arr):
     return depth | ((cn - 1) << 3)
 
 
-def camera_info(width, height, K, D, R, P):
+def camera_info(width, height, K, D, R, P, binning=(0, 0), roi=(0, 0, 0, 0)):
+    """sensor_msgs/CameraInfo as the C-ABI takes it; binning = (x, y), roi = (x_offset, y_offset, width, height), zeros = none."""
     ci = capi.CameraInfo()
     ci.width, ci.height = int(width), int(height)
+    ci.binning_x, ci.binning_y = int(binning[0]), int(binning[1])
+    ci.roi_x_offset, ci.roi_y_offset, ci.roi_width, ci.roi_height = (int(v) for v in roi)
     D = list(np.asarray(D, np.float64).reshape(-1))
     ci.nD = len(D)
     for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):

@@ -88,3 +88,43 @@ def test_calibration_ini_reader(built_lib, calib, tmp_path):
     assert (ci.width, ci.height, ci.nD, name) == (752, 480, 5, "narrow_stereo/left")
     assert np.array_equal(np.array(ci.K[:]), c["K"]) and np.array_equal(np.array(ci.D[:5]), c["D"])
     assert np.array_equal(np.array(ci.R[:]), c["R"]) and np.array_equal(np.array(ci.P[:]), c["P"])
+
+
+def test_camera_info_binning_and_roi_tables(built_lib, calib):
+    """sensor_msgs/CameraInfo binning and ROI as image_geometry applies them (fromCameraInfo / initRectificationMaps): the tables of a
+    binned camera are those of the K, P scaled by 1/binning at the binned size; an ROI takes the window of the (binned) full-frame
+    tables and subtracts its origin from the integer coordinates.  Host-only entry point, no device needed."""
+    import numpy as np
+    from oracle import oracle as O
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.processor import camera_info
+    c = calib["left"]
+    W, H = c["width"], c["height"]
+    L = capi.lib()
+
+    def tables(ci, w, h):
+        m1, m2 = np.zeros((h, w, 2), np.int16), np.zeros((h, w), np.uint16)
+        capi.check(L.gip_build_rectify_maps(ctypes.byref(ci), m1.ctypes.data, m2.ctypes.data))
+        return m1, m2
+    K, P = np.asarray(c["K"], float).reshape(3, 3), np.asarray(c["P"], float).reshape(3, 4)
+    # binning 2 x 2
+    Kb, Pb = K.copy(), P.copy()
+    Kb[0, 0] *= 0.5; Kb[0, 2] *= 0.5; Kb[1, 1] *= 0.5; Kb[1, 2] *= 0.5
+    Pb[0, 0] *= 0.5; Pb[0, 2] *= 0.5; Pb[0, 3] *= 0.5; Pb[1, 1] *= 0.5; Pb[1, 2] *= 0.5; Pb[1, 3] *= 0.5
+    e1, e2 = O.init_undistort_rectify_map(Kb.ravel(), c["D"], c["R"], Pb.ravel(), W // 2, H // 2)
+    g1, g2 = tables(camera_info(W, H, c["K"], c["D"], c["R"], c["P"], binning=(2, 2)), W // 2, H // 2)
+    assert np.array_equal(g1, e1) and np.array_equal(g2, e2)
+    # ROI on the full-resolution camera
+    f1, f2 = O.init_undistort_rectify_map(c["K"], c["D"], c["R"], c["P"], W, H)
+    rx, ry, rw, rh = 40, 24, 320, 200
+    g1, g2 = tables(camera_info(W, H, c["K"], c["D"], c["R"], c["P"], roi=(rx, ry, rw, rh)), rw, rh)
+    assert np.array_equal(g1, f1[ry:ry + rh, rx:rx + rw] - np.array([rx, ry], np.int16)) and np.array_equal(g2, f2[ry:ry + rh, rx:rx + rw])
+    # ROI + binning: ROI given in full-resolution pixels, window taken on the binned tables
+    g1, g2 = tables(camera_info(W, H, c["K"], c["D"], c["R"], c["P"], binning=(2, 2), roi=(rx, ry, rw, rh)), rw // 2, rh // 2)
+    assert np.array_equal(g1, e1[ry // 2:(ry + rh) // 2, rx // 2:(rx + rw) // 2] - np.array([rx // 2, ry // 2], np.int16))
+    assert np.array_equal(g2, e2[ry // 2:(ry + rh) // 2, rx // 2:(rx + rw) // 2])
+    # full-frame ROI given explicitly = no ROI; an ROI outside the frame is rejected
+    g1, g2 = tables(camera_info(W, H, c["K"], c["D"], c["R"], c["P"], roi=(0, 0, W, H)), W, H)
+    assert np.array_equal(g1, f1) and np.array_equal(g2, f2)
+    bad = camera_info(W, H, c["K"], c["D"], c["R"], c["P"], roi=(W - 10, 0, 64, 64))
+    assert L.gip_build_rectify_maps(ctypes.byref(bad), g1.ctypes.data, g2.ctypes.data) == capi.ERR_INVALID_ARG

@@ -246,3 +246,29 @@ def test_process_pair_schedule(proc, oracle, calib):
         q.downloadMat(P.L_COLOR)
     assert q.downloadMat(P.L_DISPARITY).shape == (h, w)
     q.close()
+
+
+def test_setters_validate_like_configcb(gpu):
+    """Setters reject values that can never be valid and leave the parameter unchanged (the reference forwards anything to
+    cv::StereoBM and fails inside compute(); its configCb fixes window and range up first, src/StereoProcessor.cpp:309-311)."""
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd import processor as P
+    p = P.GpuStereoProcessor()
+    before = p.getParams()
+    for setter, bad in ((p.setBlockSize, 8), (p.setBlockSize, 3), (p.setBlockSize, 257), (p.setNumDisparities, 40), (p.setNumDisparities, 0),
+                        (p.setPreFilterType, 2), (p.setPreFilterCap, 64), (p.setPreFilterSize, 4), (p.setTextureThreshold, -1),
+                        (p.setUniquenessRatio, -5), (p.setMaxSpeckleSize, -1), (p.setMaxSpeckleDiff, -0.5)):
+        with pytest.raises(capi.GipError) as e:
+            setter(bad)
+        assert e.value.status == capi.ERR_INVALID_ARG
+    after = p.getParams()
+    assert (before.block_size, before.num_disparities, before.prefilter_cap) == (after.block_size, after.num_disparities, after.prefilter_cap) == (19, 48, 31)
+    p.setBlockSize(21); p.setNumDisparities(64); p.setMinDisparity(-16); p.setMaxSpeckleSize(0)
+    q = p.getParams()
+    assert (q.block_size, q.num_disparities, q.min_disparity) == (21, 64, -16)
+    bad = p.getParams()
+    bad.block_size = 10
+    with pytest.raises(capi.GipError):
+        p.setParams(bad)
+    assert p.getParams().block_size == 21
+    p.close()
