@@ -27,17 +27,30 @@ ENCODING = "mono8"
 # BASELINE.json configs[1] (the one `metric` is quoted on, default) and configs[2] (north_star's second size; --workload hd1080)
 WORKLOADS = {
     # depth = batches in flight per GPU, shared = their matcher kernels go to ONE stream (both measured per workload)
-    "kitti": dict(W=1242, H=375, NDISP=128, BLOCK=9, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<8,4>", slots_per_pair=7.1,
+    "kitti": dict(W=1242, H=375, NDISP=128, BLOCK=9, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<8,4,1>",
                   name="KITTI-size 1242x375 mono8, ndisp=128 block=9, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
                        "->speckle(800,5)->f32 disparity+PointCloud2"),
-    "hd1080": dict(W=1920, H=1080, NDISP=256, BLOCK=21, ENCODING="bayer_rggb8", batch=8, depth=2, shared=False, kernel="k_bm_c4<4,10,4>", slots_per_pair=None,
+    "hd1080": dict(W=1920, H=1080, NDISP=256, BLOCK=21, ENCODING="bayer_rggb8", batch=8, depth=2, shared=False, kernel="k_bm_c4<4,10,4>",
                    name="1920x1080 bayer_rggb8, ndisp=256 block=21, full chain debayer(gray L/R + colour L)->rectify->StereoBM(XSOBEL,tex10,uniq15,"
                         "L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
-    "uhd4k": dict(W=4096, H=2160, NDISP=192, BLOCK=15, ENCODING="mono8", batch=1, depth=2, shared=False, kernel="k_bm_c4<6,7,2>", slots_per_pair=None,
+    "uhd4k": dict(W=4096, H=2160, NDISP=192, BLOCK=15, ENCODING="mono8", batch=1, depth=2, shared=False, kernel="k_bm_c4<6,7,2>",
                   name="4096x2160 mono8, ndisp=192 block=15, ONE frame per step on one GPU (BASELINE configs[4] without the row split), full chain "
                        "rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
+    # BASELINE configs[0]'s size and matcher shape (the reference's own CPU-runnable case) on the GPU path
+    "euroc": dict(W=752, H=480, NDISP=64, BLOCK=15, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<4,7,1>",
+                  name="EuRoC-size 752x480 mono8, ndisp=64 block=15, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
+    # the reference constructor's matcher shape, createStereoBM(48, 19) (reference src/GPUStereoProcessor.cpp:18-20), at the KITTI size
+    "refdefault": dict(W=1242, H=375, NDISP=48, BLOCK=19, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<3,9,1>",
+                       name="1242x375 mono8, ndisp=48 block=19 (the reference's createStereoBM(48, 19)), full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
+                            "->speckle(800,5)->f32 disparity+PointCloud2"),
 }
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0
+# Algorithmic VALU floor of an exact SAD block matcher on this ISA, in issue slots (one VOP2/VOP3 wave-instruction = 1 slot per lane)
+# per (pixel, disparity) -- DESIGN.md section 3.1: 2 row contributions (entering, leaving) at the SAD unit's 4 byte abs-diffs per slot
+# = 0.5; vertical running sum 0.5 + horizontal sliding window 1.0 + winner-take-all min 0.5 as packed-u16 instructions (2 values each).
+# It contains no index tracking, no uniqueness / texture test, no sub-pixel step and no halo work: a floor, not a target.
+VALU_FLOOR_SLOTS = 2.5
+VALU_PEAK_LANE_SLOTS = 39.3e12   # measured VOP3 issue rate, tools/ubench_valu.hip (profiles/r01_ubench_valu.txt): 4.2 cycles per wave-instruction per SIMD  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def bm_kwargs():
@@ -219,6 +232,62 @@ def e2e_streaming(lraw, rraw, calib, params, device, budget_s=1.5):
             "host_input": "pageable numpy arrays, copied into the pinned ring by the submitting thread", "records": out}
 
 
+def rowsplit_main(args, wl):
+    """BASELINE configs[4]: ONE large frame per step, cut into row tiles over the ranks (strong scaling): every rank rectifies its own
+    rows, swaps halo rows with its neighbours over RCCL point-to-point, matches its tile, takes part in the distributed speckle merge
+    (one all-gather of border rows) and produces float disparity + cloud for its rows.  `value` = frames per second of the whole job."""
+    import torch
+    import torch.distributed as dist
+    from ros_gpu_stereo_processor_amd import capi, rowsplit as RS
+    from ros_gpu_stereo_processor_amd import dist as gdist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    lraw, rraw, calib0 = make_inputs(2, seed0=100, nseeds=2)       # the same two frames on every rank (the raw frame is resident everywhere)
+    calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
+    params = capi.BMParams(**bm_kwargs())
+    from ros_gpu_stereo_processor_amd.processor import GpuStereoProcessor, camera_info
+    proc = GpuStereoProcessor(local_rank)
+    proc.initStereoModel(camera_info(W, H, **calib["left"]), camera_info(W, H, **calib["right"]))
+    Q = np.array(proc.model()["Q"], np.float64).reshape(4, 4)
+    proc.close()
+    L = [torch.from_numpy(x).to(dev) for x in lraw]
+    R = [torch.from_numpy(x).to(dev) for x in rraw]
+
+    def step(i):
+        return RS.rowsplit_frame(L[i % 2], R[i % 2], maps, params, rank, world, SPECKLE_SIZE, int(SPECKLE_DIFF * 16), Q, calib["left"]["P"][2], calib["right"]["P"][2])
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "stereo pairs/sec + ms/frame disparity, 1242x375 ndisp=128 at 1/2/4/8 GPU", "value": round(args.steps / dt, 2), "unit": "stereo pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "ms_per_frame": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": wl["name"] + " -- ROW-TILE SPLIT of one frame over %d rank(s): halo exchange (RCCL point-to-point) + distributed speckle merge" % world,
+                       "pairs_per_step": 1, "parallelism": "row-tile x%d, halo %d rows" % (world, RS.halo_rows(BLOCK))},
+            "roofline": None, "note": "host-driven per-kernel path (python launches, per-step allocations); compare with the same flags at --gpus 1"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-chain-only":   # child of cpu_baseline(): host cores only, no GPU, no torch
         n, dt, threads = _cpu_chain_timed(sys.argv[2], budget_s=float(sys.argv[3]) if len(sys.argv) > 3 else 6.0, max_pairs=100000)
@@ -235,10 +304,10 @@ def main():
     ap.add_argument("--matcher-stream", choices=["auto", "shared", "own"], default="auto", help="shared: the matcher kernels of all batches in flight go to "
                     "ONE stream and run back to back (kitti, depth 3: 49.2k pairs/s against 43.2k with own streams); own: every batch keeps its "
                     "matcher on its own stream (better for the large-disparity workloads)")
-    ap.add_argument("--alone", action="store_true", help="also time the dominant kernel with nothing else in flight (three extra untimed steps) "
-                    "and derive roofline.valu_model from it; implied by --depth 1")
     ap.add_argument("--fused-front-end", action="store_true", help="rectify + XSOBEL as ONE pass raw -> prefiltered plane (gipk_rectify_xsobel) instead of remap, then prefilter "
                     "(bit-identical; measured slower on MI355X, DESIGN.md 3.3)")
+    ap.add_argument("--rowsplit", action="store_true", help="BASELINE configs[4] mode: ONE frame per step cut into row tiles over the ranks (halo exchange + distributed "
+                    "speckle over RCCL); use with --workload uhd4k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end streaming measurement (host memory in, host memory out)")
@@ -246,6 +315,8 @@ def main():
     global W, H, NDISP, BLOCK, ENCODING
     wl = WORKLOADS[args.workload]
     W, H, NDISP, BLOCK, ENCODING = wl["W"], wl["H"], wl["NDISP"], wl["BLOCK"], wl["ENCODING"]
+    if args.rowsplit:
+        return rowsplit_main(args, wl)
     if args.batch <= 0:
         args.batch = wl["batch"]
     if args.depth <= 0:
@@ -270,7 +341,13 @@ def main():
 
     from ros_gpu_stereo_processor_amd import dist as gdist
     B = args.batch
-    lraw, rraw, calib0 = make_inputs(B, seed0=100 + 16 * rank)
+    # BASELINE configs[3]: a synthetic bag of BAG_FRAMES stereo pairs (30 s at 30 fps), frame g -> rank g mod N (dist.frame_shard), no
+    # data-path collective.  A step is one batch of B pairs PER RANK, so step i of rank r holds the bag frames
+    # ((i * B + j) * N + r) mod BAG_FRAMES, j = 0..B-1: N ranks together walk the bag front to back, each on its own shard
+    # ("weak" scaling: the per-GPU work of a step does not depend on N).  The bag cycles through NSCENES distinct synthetic scenes.
+    BAG_FRAMES, NSCENES = 900, 8
+    lscene, rscene, calib0 = make_inputs(NSCENES, seed0=100, nseeds=NSCENES)
+    lraw, rraw = lscene, rscene     # host copies (latency / e2e probes)
     # Calibration + rectification tables: rank 0 owns the CameraInfo, builds the fixed-point tables on its host (double
     # precision) and broadcasts both once over RCCL (xGMI); the other ranks run on exactly those tables.  Frames are
     # independent units (frame i -> rank i mod N, dist.frame_shard), so no collective follows on the data path.
@@ -284,13 +361,23 @@ def main():
     for p in pipes:
         p.install_maps(maps)
 
+    # every step's input batch is resident in HBM before the timed region starts (gathered from the scenes on the device)
+    scenes_l, scenes_r = torch.from_numpy(lscene).to(dev), torch.from_numpy(rscene).to(dev)
+    j = torch.arange(B, device=dev)
+
+    def step_inputs(i):
+        frames = ((i * B + j) * world + rank) % BAG_FRAMES
+        idx = frames % NSCENES
+        return scenes_l.index_select(0, idx).contiguous(), scenes_r.index_select(0, idx).contiguous()
+    nsteps_total = args.warmup + args.steps
+    inputs = [step_inputs(i) for i in range(min(nsteps_total, 32))]    # 32 distinct batches (3.8 GB at the default shape), then they repeat
+    left, right = inputs[0]
+
     def run_step(i):
         k = i % len(pipes)
+        l, r = inputs[i % len(inputs)]
         with torch.cuda.stream(streams[k]):
-            pipes[k].run(left, right, matcher_stream)
-
-    left = torch.from_numpy(lraw).to(dev)
-    right = torch.from_numpy(rraw).to(dev)
+            pipes[k].run(l, r, matcher_stream)
     torch.cuda.synchronize()
 
     def barrier():
@@ -298,7 +385,7 @@ def main():
             dist.barrier()
 
     bm_alone_ms = None
-    if args.alone and len(pipes) > 1:
+    if len(pipes) > 1:
         # the dominant kernel on its own (no second batch in flight): three synchronised steps of pipeline 0
         pipes[0].run(left, right)
         torch.cuda.synchronize()
@@ -317,11 +404,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run_step(i)
+        run_step(args.warmup + i)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    bm_ms_sum, total_ms_sum, runs = [sum(x) for x in zip(*[p.timing_read() for p in pipes])]
+    bm_ms_sum, total_ms_sum, span_ms_sum, runs = [sum(x) for x in zip(*[p.timing_read_spans() for p in pipes])]
 
     dt_max = gdist.max_over_ranks(dt, dev)
 
@@ -351,20 +438,24 @@ def main():
             "ms_per_step": round(1e3 * dt_max / args.steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * args.steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "matcher_stream": "shared" if matcher_stream is not None else "own",
-                       "parallelism": "frame-sharded x%d" % world},
+                       "parallelism": "frame-sharded x%d: frame g of a %d-frame bag -> rank g mod %d" % (world, BAG_FRAMES, world)},
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_ms": round(bm_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4),
                          # kernel_ms is the launch duration inside the timed region, where the kernels of the other batch in flight
                          # share the GPU; kernel_ms_alone is the same launch with nothing else running (three untimed steps)
                          "kernel_ms_alone": round(bm_alone_ms, 4) if bm_alone_ms else None,
-                         # the search is integer-VALU bound, not HBM bound: (pixel, disparity) pairs per second
-                         # against the measured 4.2-cycle VOP3 issue rate (tools/ubench_valu.hip: 39.3 T lane-slots/s) at the
-                         # kernel's ~7.1 issue slots per pair (weighted instruction count of k_bm_c4<8,4,1>)
-                         "valu_model": ({"px_disp_pairs_per_s": round(W * H * NDISP * B / (bm_alone_ms * 1e-3), 1),
-                                         "slots_per_pair": wl["slots_per_pair"], "peak_lane_slots_per_s": 39.3e12, "from": "kernel_ms_alone",
-                                         "frac": round(W * H * NDISP * B / (bm_alone_ms * 1e-3) * wl["slots_per_pair"] / 39.3e12, 4)
-                                         if wl["slots_per_pair"] else None} if bm_alone_ms else None)},
+                         # the search is integer-VALU / latency bound, not HBM bound: (pixel, disparity) pairs per
+                         # second times a FIXED algorithmic floor of issue slots per pair, against the measured VALU issue rate
+                         "valu_algorithmic": ({"px_disp_pairs_per_s": round(W * H * NDISP * B / (bm_alone_ms * 1e-3), 1), "floor_slots_per_px_disp": VALU_FLOOR_SLOTS,
+                                               "peak_lane_slots_per_s": VALU_PEAK_LANE_SLOTS, "from": "kernel_ms_alone",
+                                               "frac": round(W * H * NDISP * B / (bm_alone_ms * 1e-3) * VALU_FLOOR_SLOTS / VALU_PEAK_LANE_SLOTS, 4)} if bm_alone_ms else None),
+                         # SURVEY.md 8(d)'s figure for "the remap+SAD kernel": 16 bytes per pixel (2 raw + 12 map + 2 disparity), here over the SPAN
+                         # of the launches that do that work (rectify x2, prefilter x2, matcher, validateDisparity), events on the batch's stream
+                         "remap_sad_span": {"algorithmic_bytes_per_launch_set": 16.0 * W * H * B, "span_ms": round(span_ms_sum / max(runs, 1), 4),
+                                            "achieved": round(16.0 * W * H * B / (span_ms_sum / max(runs, 1) * 1e-3) / 1e9, 2) if span_ms_sum > 0 else None,
+                                            "frac": round(16.0 * W * H * B / (span_ms_sum / max(runs, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if span_ms_sum > 0 else None,
+                                            "note": "not one kernel: remap inside the matcher would re-gather every pixel 3-4x in the VALU-critical kernel (DESIGN.md 3.3)"}},
         }
         if world == 1 and not args.no_latency:
             out["latency"] = single_pair_latency(lraw[0], rraw[0], calib, params, local_rank)

@@ -358,6 +358,19 @@ int gipk_disparity_to_f32(const int16_t *disp, size_t disp_pitch, float *dst, si
 size_t gipk_speckle_scratch_bytes(int w, int h, int batch);
 int gipk_filter_speckles(int16_t *disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff,
                          void *scratch, size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream);
+/* The two phases of the filter, for a frame that is split into row tiles over several GPUs (BASELINE configs[4]): label = find the
+ * components of this tile and their sizes; row_labels = per pixel of one row the id of its component's root (-1: invalid pixel) and
+ * the size stored there; set_sizes = overwrite the sizes of given roots (with the size of the whole component once the ranks have
+ * merged the components that touch the tile borders); apply = erase components of at most max_speckle_size pixels.
+ * gipk_filter_speckles = label + apply. */
+int gipk_speckle_label(const int16_t *disp, size_t disp_pitch, int w, int h, int new_val, int max_diff, void *scratch, size_t scratch_bytes,
+                       int batch, size_t disp_bstride, gip_stream stream);
+int gipk_speckle_row_labels(void *scratch, size_t scratch_bytes, int w, int h, int batch, int row, int32_t *root_out, int32_t *size_out,
+                            gip_stream stream);
+int gipk_speckle_set_sizes(void *scratch, size_t scratch_bytes, int w, int h, int batch, const int32_t *roots, const int32_t *sizes, int n,
+                           gip_stream stream);
+int gipk_speckle_apply(int16_t *disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, void *scratch,
+                       size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream);
 
 /* reprojectImageTo3D on the float disparity (missing = the image minimum, i.e. `missing_value`) */
 int gipk_reproject_to_3d(const float *disp, size_t disp_pitch, float *xyz, size_t xyz_pitch, int w, int h, const double Q[16],
@@ -408,6 +421,10 @@ int gip_batch_last_kernel_ms(gip_handle h, float *bm_ms, float *total_ms);
  * The stream(s) used must have been synchronised before reading. */
 int gip_batch_timing_reset(gip_handle h);
 int gip_batch_timing_read(gip_handle h, double *bm_ms_sum, double *total_ms_sum, int *runs);
+/* the same plus the "remap + SAD" span of every run: from the start of the chain to the end of validateDisparity (colour
+ * conversion, rectify, prefilter, matcher, L/R check) -- the stages whose compulsory HBM traffic is the 16 bytes per pixel of
+ * SURVEY.md section 8(d) */
+int gip_batch_timing_read_spans(gip_handle h, double *bm_ms_sum, double *total_ms_sum, double *remap_sad_ms_sum, int *runs);
 
 #ifdef __cplusplus
 }

@@ -174,6 +174,10 @@ PROTOTYPES = {
     "gipk_disparity_to_f32": (_i, [_vp, _sz, _vp, _sz, _i, _i, _d, _d, _i, _sz, _sz, _vp]),
     "gipk_speckle_scratch_bytes": (_sz, [_i, _i, _i]),
     "gipk_filter_speckles": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _vp, _sz, _i, _sz, _vp]),
+    "gipk_speckle_label": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _sz, _i, _sz, _vp]),
+    "gipk_speckle_row_labels": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "gipk_speckle_set_sizes": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "gipk_speckle_apply": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _sz, _i, _sz, _vp]),
     "gipk_reproject_to_3d": (_i, [_vp, _sz, _vp, _sz, _i, _i, C.POINTER(_d), C.c_float, _i, _i, _sz, _sz, _vp]),
     "gipk_pack_pointcloud2": (_i, [_vp, _sz, _vp, _sz, _vp, _i, _i, _i, _sz, _sz, _sz, _vp]),
     "gipk_disparity_to_pointcloud2": (_i, [_vp, _sz, _vp, _sz, _vp, _i, _i, C.POINTER(_d), _d, _d, _i, _i, _sz, _sz, _sz, _vp]),
@@ -190,6 +194,7 @@ PROTOTYPES = {
     "gip_streamer_close": (_i, [_vp]),
     "gip_streamer_last_error": (C.c_char_p, [_vp]),
     "gip_batch_timing_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
+    "gip_batch_timing_read_spans": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
 }
 
 _LIB = None

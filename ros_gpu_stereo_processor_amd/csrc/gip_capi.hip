@@ -105,7 +105,7 @@ struct gip_processor {
     std::vector<std::pair<void*, size_t>> pinned_pool;
     // batch pipeline
     DevBuf b_mono[2], b_color, b_rect[2], b_rect_color, b_f32;
-    // per-run timing events of the batch pipeline: 4 per run (bm0, bm1, total0, total1), grown on demand
+    // per-run timing events of the batch pipeline: 5 per run (bm0, bm1, total0, total1, end of rectify+prefilter+match+validate), grown on demand
     std::vector<hipEvent_t> tev;
     int timing_runs = 0;
 };
@@ -1159,12 +1159,12 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     bp.speckle_window_size = 0;  // the node-level speckle filter below is the one the reference runs
 #define B_STEP(expr, what) do { rc = (expr); if (rc != GIP_OK) return propagate(h, rc, what); } while (0)
     if (h->timing_runs >= 4096) h->timing_runs = 0;  // ring: the caller is expected to read/reset well before this
-    while ((int)h->tev.size() < 4 * (h->timing_runs + 1)) {
+    while ((int)h->tev.size() < 5 * (h->timing_runs + 1)) {
         hipEvent_t e;
         H_HIP(h, hipEventCreate(&e));
         h->tev.push_back(e);
     }
-    hipEvent_t* ev = &h->tev[4 * h->timing_runs];
+    hipEvent_t* ev = &h->tev[5 * h->timing_runs];
     H_HIP(h, hipEventRecord(ev[2], st));
     // stage 1: colour (StereoProcessor.cpp:183-217)
     const uint8_t* mono[2] = {d->left_raw, d->right_raw};
@@ -1249,6 +1249,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     // both prefiltered planes are in the scratch already (null inputs)
     rc = gip_stereobm_impl(nullptr, nullptr, pfp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, pfplane, npx * 2, st, &mctx);
     if (rc != GIP_OK) return propagate(h, rc, "stereobm");
+    H_HIP(h, hipEventRecord(ev[4], st));   // end of the "remap + SAD" span: colour, rectify, prefilter, matcher, validateDisparity
     if (h->max_speckle_size > 0) {
         B_STEP(ensure_dev(h, h->spk_scratch, gipk_speckle_scratch_bytes(w, hh, B)), "batch buffers");
         B_STEP(gipk_filter_speckles(d->disparity, (size_t)w * 2, w, hh, (bp.min_disparity - 1) * 16, h->max_speckle_size, (int)(h->max_speckle_diff * 16.0), h->spk_scratch.p,
@@ -1269,7 +1270,7 @@ int gip_batch_last_kernel_ms(gip_handle h, float* bm_ms, float* total_ms)
 {
     H_CHECK(h);
     if (h->timing_runs <= 0) return fail(h, GIP_ERR_INVALID_ARG, "no batch has run");
-    hipEvent_t* ev = &h->tev[4 * (h->timing_runs - 1)];
+    hipEvent_t* ev = &h->tev[5 * (h->timing_runs - 1)];
     if (bm_ms) H_HIP(h, hipEventElapsedTime(bm_ms, ev[0], ev[1]));
     if (total_ms) H_HIP(h, hipEventElapsedTime(total_ms, ev[2], ev[3]));
     return GIP_OK;
@@ -1282,19 +1283,24 @@ int gip_batch_timing_reset(gip_handle h)
     return GIP_OK;
 }
 
-int gip_batch_timing_read(gip_handle h, double* bm_ms_sum, double* total_ms_sum, int* runs)
+int gip_batch_timing_read(gip_handle h, double* bm_ms_sum, double* total_ms_sum, int* runs) { return gip_batch_timing_read_spans(h, bm_ms_sum, total_ms_sum, nullptr, runs); }
+
+int gip_batch_timing_read_spans(gip_handle h, double* bm_ms_sum, double* total_ms_sum, double* remap_sad_ms_sum, int* runs)
 {
     H_CHECK(h);
-    double a = 0, b = 0;
+    double a = 0, b = 0, c = 0;
     for (int i = 0; i < h->timing_runs; i++) {
-        float x = 0, y = 0;
-        H_HIP(h, hipEventElapsedTime(&x, h->tev[4 * i], h->tev[4 * i + 1]));
-        H_HIP(h, hipEventElapsedTime(&y, h->tev[4 * i + 2], h->tev[4 * i + 3]));
+        float x = 0, y = 0, z = 0;
+        H_HIP(h, hipEventElapsedTime(&x, h->tev[5 * i], h->tev[5 * i + 1]));
+        H_HIP(h, hipEventElapsedTime(&y, h->tev[5 * i + 2], h->tev[5 * i + 3]));
+        H_HIP(h, hipEventElapsedTime(&z, h->tev[5 * i + 2], h->tev[5 * i + 4]));
         a += x;
         b += y;
+        c += z;
     }
     if (bm_ms_sum) *bm_ms_sum = a;
     if (total_ms_sum) *total_ms_sum = b;
+    if (remap_sad_ms_sum) *remap_sad_ms_sum = c;
     if (runs) *runs = h->timing_runs;
     return GIP_OK;
 }

@@ -527,6 +527,32 @@ __global__ void __launch_bounds__(64) k_spk_apply(int16_t* __restrict__ disp, si
     }
 }
 
+// Labels of one image row after k_spk_sizes: per pixel the GLOBAL root node of its component (-1 for invalid pixels) and the size
+// stored there.  Used by the row-tile split (rowsplit.py): components that touch a tile's first / last row continue in the
+// neighbouring rank's tile; the ranks exchange these rows, merge the touching components and patch the sizes of their own roots
+// (k_spk_set_sizes) before k_spk_apply.
+__global__ void __launch_bounds__(256) k_spk_row_labels(SpkScratch S, int w, int h, int y, int* __restrict__ root_out, int* __restrict__ size_out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const size_t ibase = blockIdx.z * (size_t)w * h;
+    const unsigned ord = S.ord16[ibase + (size_t)y * w + x];
+    int root = -1, size = 0;
+    if (ord != 0xFFFFu) {
+        const int r1 = S.parent[ibase + (size_t)y * w + ord];
+        root = S.parent[ibase + r1];
+        size = S.csize[ibase + root];
+    }
+    root_out[blockIdx.z * (size_t)w + x] = root;
+    size_out[blockIdx.z * (size_t)w + x] = size;
+}
+
+__global__ void __launch_bounds__(256) k_spk_set_sizes(SpkScratch S, const int* __restrict__ roots, const int* __restrict__ sizes, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) S.csize[roots[i]] = sizes[i];
+}
+
 // ---------------------------------------------------------------------------------------- reprojection / cloud
 struct QMat { double q[16]; };
 
@@ -717,33 +743,84 @@ int gipk_disparity_to_f32(const int16_t* disp, size_t disp_pitch, float* dst, si
 
 size_t gipk_speckle_scratch_bytes(int w, int h, int batch) { return (size_t)w * h * batch * 18 + (size_t)h * batch * 12 + 64; }
 
-int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff, void* scratch,
-                         size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream)
+static int spk_carve(void* scratch, size_t scratch_bytes, int w, int h, int batch, SpkScratch* S)
 {
-    GIPK_ARGCHECK(disp && scratch && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
-    GIPK_ARGCHECK(scratch_bytes >= gipk_speckle_scratch_bytes(w, h, batch) && (size_t)w * h < (1u << 31));
+    if (!scratch || scratch_bytes < gipk_speckle_scratch_bytes(w, h, batch) || (size_t)w * h >= (1u << 31)) return GIP_ERR_INVALID_ARG;
     if (w > 32768) return GIP_ERR_UNSUPPORTED;
     const size_t n = (size_t)w * h * batch;
-    const int nstrips = (h + SPK_STRIP - 1) / SPK_STRIP;
+    S->parent = (int*)gip_align_up((size_t)(uintptr_t)scratch, 16);
+    S->csize = S->parent + n;
+    S->runlist = (u32*)(S->csize + n);
+    S->joinlist = S->runlist + n;
+    S->nrun = (int*)(S->joinlist + n);
+    S->njoin = S->nrun + (size_t)h * batch;
+    S->global_strip = S->njoin + (size_t)h * batch;    // nstrips * batch <= h * batch entries
+    S->ord16 = (unsigned short*)(S->global_strip + (size_t)h * batch);
+    return GIP_OK;
+}
+
+// phase 1 of cv::filterSpeckles: label the components and leave their sizes at the global roots (no pixel is changed)
+int gipk_speckle_label(const int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_diff, void* scratch, size_t scratch_bytes, int batch,
+                       size_t disp_bstride, gip_stream stream)
+{
+    GIPK_ARGCHECK(disp && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
     SpkScratch S;
-    S.parent = (int*)gip_align_up((size_t)(uintptr_t)scratch, 16);
-    S.csize = S.parent + n;
-    S.runlist = (u32*)(S.csize + n);
-    S.joinlist = S.runlist + n;
-    S.nrun = (int*)(S.joinlist + n);
-    S.njoin = S.nrun + (size_t)h * batch;
-    S.global_strip = S.njoin + (size_t)h * batch;    // nstrips * batch <= h * batch entries
-    S.ord16 = (unsigned short*)(S.global_strip + (size_t)h * batch);
+    int rc = spk_carve(scratch, scratch_bytes, w, h, batch, &S);
+    if (rc != GIP_OK) return rc;
+    const int nstrips = (h + SPK_STRIP - 1) / SPK_STRIP;
     hipStream_t st = (hipStream_t)stream;
-const bool pairs_ok = (w % 2 == 0) && (disp_pitch % 4 == 0) && ((uintptr_t)disp % 4 == 0) && (disp_bstride % 4 == 0) && ((uintptr_t)S.ord16 % 4 == 0);
+    const bool pairs_ok = (w % 2 == 0) && (disp_pitch % 4 == 0) && ((uintptr_t)disp % 4 == 0) && (disp_bstride % 4 == 0) && ((uintptr_t)S.ord16 % 4 == 0);
     if (pairs_ok) hipLaunchKernelGGL(k_spk_scan2, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     else hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     hipLaunchKernelGGL(k_spk_strip, dim3(nstrips, 1, batch), dim3(SPK_TPB), (size_t)SPK_CAP * 8, st, S, w, h, nstrips);
     if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(64), 0, st, S, w, h, nstrips);
     hipLaunchKernelGGL(k_spk_sizes, dim3(h, 1, batch), dim3(64), 0, st, S, w, h);
-    hipLaunchKernelGGL(k_spk_apply, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_speckle_size, disp_bstride);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
+}
+
+// phase 2: erase the components whose size (as stored at their roots) is <= max_speckle_size
+int gipk_speckle_apply(int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, void* scratch, size_t scratch_bytes, int batch,
+                       size_t disp_bstride, gip_stream stream)
+{
+    GIPK_ARGCHECK(disp && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
+    SpkScratch S;
+    int rc = spk_carve(scratch, scratch_bytes, w, h, batch, &S);
+    if (rc != GIP_OK) return rc;
+    hipLaunchKernelGGL(k_spk_apply, dim3(h, 1, batch), dim3(64), 0, (hipStream_t)stream, disp, disp_pitch / 2, S, w, h, new_val, max_speckle_size, disp_bstride);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
+int gipk_speckle_row_labels(void* scratch, size_t scratch_bytes, int w, int h, int batch, int row, int32_t* root_out, int32_t* size_out, gip_stream stream)
+{
+    GIPK_ARGCHECK(root_out && size_out && w > 0 && h > 0 && batch > 0 && row >= 0 && row < h);
+    SpkScratch S;
+    int rc = spk_carve(scratch, scratch_bytes, w, h, batch, &S);
+    if (rc != GIP_OK) return rc;
+    hipLaunchKernelGGL(k_spk_row_labels, dim3(gip_div_up(w, 256), 1, batch), dim3(256), 0, (hipStream_t)stream, S, w, h, row, root_out, size_out);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
+int gipk_speckle_set_sizes(void* scratch, size_t scratch_bytes, int w, int h, int batch, const int32_t* roots, const int32_t* sizes, int n, gip_stream stream)
+{
+    GIPK_ARGCHECK(w > 0 && h > 0 && batch == 1 && n >= 0 && (n == 0 || (roots && sizes)));
+    if (n == 0) return GIP_OK;
+    SpkScratch S;
+    int rc = spk_carve(scratch, scratch_bytes, w, h, batch, &S);
+    if (rc != GIP_OK) return rc;
+    hipLaunchKernelGGL(k_spk_set_sizes, dim3(gip_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, S, roots, sizes, n);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
+int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff, void* scratch,
+                         size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream)
+{
+    int rc = gipk_speckle_label(disp, disp_pitch, w, h, new_val, max_diff, scratch, scratch_bytes, batch, disp_bstride, stream);
+    if (rc != GIP_OK) return rc;
+    return gipk_speckle_apply(disp, disp_pitch, w, h, new_val, max_speckle_size, scratch, scratch_bytes, batch, disp_bstride, stream);
 }
 
 int gipk_reproject_to_3d(const float* disp, size_t disp_pitch, float* xyz, size_t xyz_pitch, int w, int h, const double Q[16], float missing_value,

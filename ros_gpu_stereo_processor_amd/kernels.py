@@ -5,6 +5,7 @@ on the tensors' storage.  Inputs are (B, H, W[, C]) or (H, W[, C]) contiguous CU
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import capi
@@ -170,6 +171,38 @@ def filter_speckles(disp, new_val, max_speckle_size, max_diff):
     return disp
 
 
+class SpeckleLabels:
+    """Phase 1 of the speckle filter on ONE (H,W) int16 disparity tile: component labels and sizes in device scratch."""
+
+    def __init__(self, disp, new_val, max_diff):
+        assert disp.dim() == 2 and disp.dtype == torch.int16 and disp.is_contiguous()
+        self.L = capi.lib()
+        self.disp, self.H, self.W, self.new_val = disp, disp.shape[0], disp.shape[1], int(new_val)
+        self.nbytes = self.L.gipk_speckle_scratch_bytes(self.W, self.H, 1)
+        self.scratch = torch.empty(self.nbytes, dtype=torch.uint8, device=disp.device)
+        _ck(self.L.gipk_speckle_label(disp.data_ptr(), self.W * 2, self.W, self.H, self.new_val, int(max_diff), self.scratch.data_ptr(), self.nbytes, 1, self.H * self.W * 2,
+                                      _stream()))
+
+    def row_labels(self, row):
+        """(roots int32[W] (-1 = invalid pixel), sizes int32[W]) of one row"""
+        roots = torch.empty(self.W, dtype=torch.int32, device=self.disp.device)
+        sizes = torch.empty(self.W, dtype=torch.int32, device=self.disp.device)
+        _ck(self.L.gipk_speckle_row_labels(self.scratch.data_ptr(), self.nbytes, self.W, self.H, 1, int(row), roots.data_ptr(), sizes.data_ptr(), _stream()))
+        return roots, sizes
+
+    def set_sizes(self, roots, sizes):
+        if len(roots) == 0:
+            return
+        r = torch.as_tensor(roots, dtype=torch.int32, device=self.disp.device).contiguous()
+        z = torch.as_tensor(sizes, dtype=torch.int32, device=self.disp.device).contiguous()
+        _ck(self.L.gipk_speckle_set_sizes(self.scratch.data_ptr(), self.nbytes, self.W, self.H, 1, r.data_ptr(), z.data_ptr(), r.numel(), _stream()))
+
+    def apply(self, max_speckle_size):
+        _ck(self.L.gipk_speckle_apply(self.disp.data_ptr(), self.W * 2, self.W, self.H, self.new_val, int(max_speckle_size), self.scratch.data_ptr(), self.nbytes, 1,
+                                      self.H * self.W * 2, _stream()))
+        return self.disp
+
+
 def _q(Q):
     return (C.c_double * 16)(*[float(v) for v in Q.reshape(-1)])
 
@@ -206,6 +239,23 @@ def disparity_to_pointcloud2(disp, bgr, Q, cx_l, cx_r, min_disparity):
     _ck(L.gipk_disparity_to_pointcloud2(d.data_ptr(), W * 2, cptr, W * 3, out.data_ptr(), W, H, _q(Q), float(cx_l), float(cx_r), int(min_disparity), B,
                                         H * W * 2, H * W * 3, H * W * 32, _stream()))
     return out if disp.dim() == 3 else out[0]
+
+
+def disparity_outputs(disp, colour, Q, cx_l, cx_r, min_disparity, want_f32=True, want_cloud=True):
+    """Fused tail of the chain on ONE (H,W) int16 disparity: float disparity d/16 - (cx_l - cx_r) and the 32-byte PointCloud2 records.
+    colour: (H,W) mono (replicated, = GRAY2BGR) or (H,W,3) BGR rectified image, or None."""
+    L = capi.lib()
+    assert disp.dim() == 2 and disp.is_contiguous()
+    H, W = disp.shape
+    f32 = torch.empty((H, W), dtype=torch.float32, device=disp.device) if want_f32 else None
+    pc = torch.empty((H, W, 32), dtype=torch.uint8, device=disp.device) if want_cloud else None
+    cn = 0 if colour is None else (3 if colour.dim() == 3 else 1)
+    if colour is not None:
+        assert colour.is_contiguous() and colour.shape[0] == H and colour.shape[1] == W
+    _ck(L.gipk_disparity_outputs(disp.data_ptr(), W * 2, colour.data_ptr() if colour is not None else None, W * cn, cn if cn else 3, f32.data_ptr() if want_f32 else None,
+                                 pc.data_ptr() if want_cloud else None, W, H, _q(np.asarray(Q, np.float64)), float(cx_l), float(cx_r), int(min_disparity), 1, H * W * 2,
+                                 H * W * cn, _stream()))
+    return f32, pc
 
 
 def draw_color_disp(disp, ndisp):

@@ -74,5 +74,11 @@ class BatchPipeline:
         capi.check(self._lib.gip_batch_timing_read(self.proc.handle, C.byref(a), C.byref(b), C.byref(n)), self.proc.handle)
         return a.value, b.value, n.value
 
+    def timing_read_spans(self):
+        """(matcher ms, whole-chain ms, remap+SAD span ms, runs) summed over the runs since the last reset"""
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        capi.check(self._lib.gip_batch_timing_read_spans(self.proc.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(n)), self.proc.handle)
+        return a.value, b.value, c.value, n.value
+
     def close(self):
         self.proc.close()

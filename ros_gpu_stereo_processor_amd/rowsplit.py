@@ -4,12 +4,16 @@ Block matching is row-local apart from the vertical extent of its windows, so ra
 `halo` extra RECTIFIED rows above and below:  halo = block radius + 1 (the XSOBEL prefilter is a 3x3 operator; for
 NORMALIZED_RESPONSE it is block radius + prefilter radius + 1).  Each rank rectifies its own rows, swaps the boundary rows
 with its neighbours (point-to-point over xGMI: RCCL send/recv, 2 x halo x W bytes per boundary and image), runs the matcher
-on its extended tile, keeps the rows whose windows never touched the tile's artificial top/bottom border, and the disparity
-tiles are gathered on rank 0, where the (global) speckle filter and the cloud kernel run.  The L/R consistency check is
-row-local and needs nothing extra.
+on its extended tile and keeps the rows whose windows never touched the tile's artificial top/bottom border.  The L/R
+consistency check is row-local and needs nothing extra.  The speckle filter is global (a component may cross tile borders):
+every rank labels the components of its own rows, the ranks all-gather their first and last rows (value, component root, component
+size: 10 bytes per pixel), every rank merges the components that touch across a border with a small host union-find, patches the
+sizes of its own border components to the size of the whole component and erases what is small (distributed_speckle below; the
+single exchange of SURVEY.md section 8(e)).  Cloud and float disparity are produced per tile.
 
 The same functions drive the single-GPU parity test (ranks simulated one after the other) and the gloo test of the exchange.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -114,3 +118,118 @@ def split_stereobm_simulated(rect_l, rect_r, params, world_size, block_size, pre
         d = match_tile(rect_l[e0:e1].contiguous(), rect_r[e0:e1].contiguous(), params)
         out[y0:y1] = crop_valid(d, h, y0, y1, halo)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ speckle
+def _connected(a, b, new_val, max_diff):
+    return (a != new_val) & (b != new_val) & (np.abs(a.astype(np.int64) - b.astype(np.int64)) <= max_diff)
+
+
+def merge_border_components(rows, new_val, max_diff):
+    """rows[t] = (top_vals, top_roots, top_sizes, bot_vals, bot_roots, bot_sizes) of rank t (numpy, one entry per image column; roots
+    are rank-local ids, -1 for invalid pixels).  Components that touch across the border between rank t and t+1 (4-connectivity: same
+    column, both valid, |difference| <= max_diff -- cv::filterSpeckles' rule) are united; returns per rank {root: size of the whole
+    component} for every root that appears in one of its border rows."""
+    parent, size = {}, {}
+
+    def find(n):
+        while parent[n] != n:
+            parent[n] = parent[parent[n]]
+            n = parent[n]
+        return n
+    for t, (tv, tr, ts, bv, br, bs) in enumerate(rows):
+        for roots, sizes in ((tr, ts), (br, bs)):
+            valid = roots >= 0
+            for r, z in zip(*np.unique(np.stack([roots[valid], sizes[valid]]), axis=1)) if valid.any() else ():
+                parent.setdefault((t, int(r)), (t, int(r)))
+                size[(t, int(r))] = int(z)
+    for t in range(len(rows) - 1):
+        bv, br = rows[t][3], rows[t][4]
+        tv, tr = rows[t + 1][0], rows[t + 1][1]
+        con = _connected(bv, tv, new_val, max_diff) & (br >= 0) & (tr >= 0)
+        if not con.any():
+            continue
+        for a, b in zip(*np.unique(np.stack([br[con], tr[con]]), axis=1)):
+            ra, rb = find((t, int(a))), find((t + 1, int(b)))
+            if ra != rb:
+                parent[rb] = ra
+    total = {}
+    for n in parent:
+        total[find(n)] = total.get(find(n), 0) + size[n]
+    out = [dict() for _ in rows]
+    for (t, r) in parent:
+        out[t][r] = total[find((t, r))]
+    return out
+
+
+def distributed_speckle(tile, rank, world_size, new_val, max_size, max_diff, group=None, labeler=None):
+    """cv::filterSpeckles on a frame that is split into row tiles: `tile` holds this rank's rows (int16, modified in place and
+    returned).  labeler(tile, new_val, max_diff) -> object with row_labels(row) -> (roots, sizes), set_sizes(roots, sizes),
+    apply(max_size); the default is the HIP implementation (kernels.SpeckleLabels)."""
+    if labeler is None:
+        from .kernels import SpeckleLabels as labeler
+    lab = labeler(tile, new_val, max_diff)
+    if world_size > 1:
+        h = tile.shape[0]
+        tr, ts = lab.row_labels(0)
+        br, bs = lab.row_labels(h - 1)
+        mine = torch.stack([tile[0].to(torch.int32), tr.to(torch.int32), ts.to(torch.int32), tile[h - 1].to(torch.int32), br.to(torch.int32), bs.to(torch.int32)])
+        everyone = [torch.empty_like(mine) for _ in range(world_size)]
+        dist.all_gather(everyone, mine, group=group)
+        rows = [tuple(e.cpu().numpy()) for e in everyone]
+        patch = merge_border_components(rows, new_val, max_diff)[rank]
+        if patch:
+            lab.set_sizes(list(patch.keys()), list(patch.values()))
+    return lab.apply(max_size)
+
+
+def split_speckle_simulated(disp, world_size, new_val, max_size, max_diff):
+    """Single-process rehearsal of distributed_speckle on the HIP labeler: every 'rank' labels its own rows, the border rows are
+    merged exactly as the ranks would after the all-gather, sizes patched, tiles erased and stitched."""
+    from .kernels import SpeckleLabels
+    h = disp.shape[0]
+    ranges = plan(h, world_size)
+    tiles = [disp[a:b].contiguous().clone() for a, b in ranges]
+    labs = [SpeckleLabels(t, new_val, max_diff) for t in tiles]
+    rows = []
+    for t, lab in zip(tiles, labs):
+        tr, ts = lab.row_labels(0)
+        br, bs = lab.row_labels(t.shape[0] - 1)
+        rows.append(tuple(x.cpu().numpy().astype(np.int32) for x in (t[0], tr, ts, t[-1], br, bs)))
+    patches = merge_border_components(rows, new_val, max_diff)
+    for lab, patch in zip(labs, patches):
+        if patch:
+            lab.set_sizes(list(patch.keys()), list(patch.values()))
+        lab.apply(max_size)
+    return torch.cat(tiles, 0)
+
+
+def rowsplit_frame(raw_l, raw_r, maps, params, rank, world_size, speckle_size, speckle_diff16, Q=None, cx_l=0.0, cx_r=0.0, group=None, want_cloud=True):
+    """One frame of BASELINE configs[4] on this rank: rectify the rank's own rows of both eyes (the raw frame is resident on every
+    rank), swap halo rows with the neighbours, match the extended tile (StereoBM incl. L/R check), keep the rank's rows, run the
+    distributed speckle filter, and produce float disparity + cloud for the rank's rows.  Returns (y0, y1, disparity int16 tile,
+    float tile or None, cloud tile or None).  maps = [map1_l, map2_l, map1_r, map2_r] full-frame device tensors."""
+    from . import kernels as K
+    h, w = raw_l.shape
+    halo = halo_rows(params.block_size, params.prefilter_type, params.prefilter_size)
+    ranges = plan(h, world_size)
+    y0, y1 = ranges[rank]
+    rl = K.remap(raw_l, maps[0][y0:y1], maps[1][y0:y1])
+    rr = K.remap(raw_r, maps[2][y0:y1], maps[3][y0:y1])
+    if world_size > 1:
+        rl = exchange_halos(rl, rank, world_size, ranges, h, halo, group)
+        rr = exchange_halos(rr, rank, world_size, ranges, h, halo, group)
+    d = crop_valid(match_tile(rl.contiguous(), rr.contiguous(), params), h, y0, y1, halo).contiguous()
+    if world_size == 1:
+        d = d.clone()
+    if speckle_size > 0:
+        d = distributed_speckle(d, rank, world_size, (params.min_disparity - 1) * 16, speckle_size, speckle_diff16, group)
+    f32 = cloud = None
+    if want_cloud and Q is not None:
+        # the reprojection depends on the row index: shift the row terms of Q by the tile origin (q.. + q.. * y0)
+        Qt = np.array(Q, np.float64).reshape(4, 4).copy()
+        Qt[:, 3] += Qt[:, 1] * y0
+        e0, _ = extended_range(h, y0, y1, halo)
+        colour = rl[y0 - e0:y1 - e0].contiguous()
+        f32, cloud = K.disparity_outputs(d, colour, Qt, cx_l, cx_r, params.min_disparity)
+    return y0, y1, d, f32, cloud

@@ -97,3 +97,100 @@ def test_rowsplit_halo_exchange_world3():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+class _CpuLabels:
+    """Host stand-in for kernels.SpeckleLabels (the merge logic of rowsplit.distributed_speckle is device-agnostic): components of
+    ONE tile by flood fill with cv::filterSpeckles' connectivity rule; roots are arbitrary tile-local ids."""
+
+    def __init__(self, tile, new_val, max_diff):
+        self.tile, self.new_val = tile, new_val
+        a = tile.numpy().astype(np.int64)
+        h, w = a.shape
+        self.lab = -np.ones((h, w), np.int64)
+        self.sizes = {}
+        nxt = 0
+        for y in range(h):
+            for x in range(w):
+                if a[y, x] == new_val or self.lab[y, x] >= 0:
+                    continue
+                rid = 1000 + 7 * nxt      # deliberately not dense / not zero based
+                nxt += 1
+                stack, n = [(y, x)], 0
+                self.lab[y, x] = rid
+                while stack:
+                    cy, cx = stack.pop()
+                    n += 1
+                    for ny, nx in ((cy - 1, cx), (cy + 1, cx), (cy, cx - 1), (cy, cx + 1)):
+                        if 0 <= ny < h and 0 <= nx < w and self.lab[ny, nx] < 0 and a[ny, nx] != new_val and abs(a[ny, nx] - a[cy, cx]) <= max_diff:
+                            self.lab[ny, nx] = rid
+                            stack.append((ny, nx))
+                self.sizes[rid] = n
+
+    def row_labels(self, row):
+        r = self.lab[row]
+        return torch.from_numpy(r.astype(np.int32)), torch.from_numpy(np.array([self.sizes.get(int(v), 0) for v in r], np.int32))
+
+    def set_sizes(self, roots, sizes):
+        for r, z in zip(roots, sizes):
+            self.sizes[int(r)] = int(z)
+
+    def apply(self, max_size):
+        a = self.tile.numpy()
+        for rid, n in self.sizes.items():
+            if n <= max_size:
+                a[self.lab == rid] = self.new_val
+        return self.tile
+
+
+def _speckle_frame():
+    """valid background with speckles of known sizes, several of them straddling the tile borders of a 3-way split (rows 14, 28):
+    a 5 x 3 blob across row 14 (15 px: removed at max_size 16 although each half is smaller AND bigger cases), a tall 1-px snake through
+    two borders (30 px: kept), a blob that only touches a border row."""
+    rng = np.random.default_rng(4)
+    h, w = 42, 40
+    a = np.full((h, w), -16, np.int16)
+    a[2:40, 2:38] = (rng.integers(0, 2, (38, 36)) * 640 + 160).astype(np.int16)      # two-level noise: many small components
+    a[12:17, 5:8] = 3000                                                                # 15 px across the first border
+    a[6:36, 20] = 5000                                                                  # 30 px snake across both borders
+    a[26:28, 30:34] = 7000                                                              # 8 px ending ON the last row of tile 1
+    a[28:30, 30:32] = 7016                                                              # 4 px, connected to it through the border (|diff| 16)
+    return a
+
+
+def _speckle_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ros_gpu_stereo_processor_amd import rowsplit as RS
+    full = _speckle_frame()
+    ranges = RS.plan(full.shape[0], world)
+    y0, y1 = ranges[rank]
+    tile = torch.from_numpy(full[y0:y1].copy())
+    out = RS.distributed_speckle(tile, rank, world, -16, 16, 32, labeler=_CpuLabels)
+    q.put((rank, y0, y1, out.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_speckle_world3(oracle):
+    """Row-tile split, speckle filter: every rank labels its own rows, one all-gather of the border rows, host merge of the components
+    that touch across a border, sizes patched, then the local erase -- stitched result == cv::filterSpeckles on the whole frame."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_speckle_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = _speckle_frame()
+    got = np.concatenate([r[3] for r in res], 0)
+    exp = oracle.filter_speckles(full.copy(), -16, 16, 32)
+    assert np.array_equal(got, exp)
+    assert (exp[12:17, 5:8] == -16).all() and (exp[6:36, 20] == 5000).all() and (exp[26:28, 30:34] == -16).all()   # 15 px gone, 30 px kept, 8+4 px gone
+    # and per-tile filtering WITHOUT the exchange would be wrong (the test frame really exercises the merge)
+    naive = np.concatenate([oracle.filter_speckles(full[a:b].copy(), -16, 16, 32) for a, b in [(r[1], r[2]) for r in res]], 0)
+    assert not np.array_equal(naive, exp)

@@ -236,3 +236,76 @@ def test_batch_pipeline_fused_front_end_equals_two_pass(gpu, prefilter_type):
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.gpu
+def test_rowsplit_speckle_simulated_ranks(gpu, oracle):
+    """configs[4] speckle stage on the HIP labeler: a frame cut into 2, 3 and 5 row tiles, components merged across the tile borders
+    from the exported border labels (what the ranks all-gather), equals the filter on the whole frame -- on a real disparity map and
+    on the synthetic frame whose speckles straddle the borders."""
+    import torch
+    from ros_gpu_stereo_processor_amd import kernels as K, rowsplit as RS
+    w, h, nd = 420, 150, 48
+    l, r, _ = synth.rectified_pair(w, h, nd, seed=77)
+    po = oracle.bm_params(block_size=9, num_disparities=nd, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1)
+    d = oracle.stereobm(l, r, po)
+    frames = [(d, 60, 32)]
+    rng = np.random.default_rng(4)
+    a = np.full((42, 40), -16, np.int16)
+    a[2:40, 2:38] = (rng.integers(0, 2, (38, 36)) * 640 + 160).astype(np.int16)
+    a[12:17, 5:8] = 3000
+    a[6:36, 20] = 5000
+    a[26:28, 30:34] = 7000
+    a[28:30, 30:32] = 7016
+    frames.append((a, 16, 32))
+    for frame, max_size, max_diff in frames:
+        exp = oracle.filter_speckles(frame.copy(), -16, max_size, max_diff)
+        whole = K.filter_speckles(torch.from_numpy(frame.copy()).to(gpu), -16, max_size, max_diff)
+        assert np.array_equal(whole.cpu().numpy(), exp)
+        for world in (2, 3, 5):
+            got = RS.split_speckle_simulated(torch.from_numpy(frame.copy()).to(gpu), world, -16, max_size, max_diff)
+            assert np.array_equal(got.cpu().numpy(), exp), world
+
+
+@pytest.mark.gpu
+def test_rowsplit_frame_single_rank_equals_pipeline(gpu, oracle):
+    """rowsplit.rowsplit_frame (the per-rank step of `bench.py --rowsplit`) with world size 1: rectify, match, speckle, cloud of the whole
+    frame through the same code path the ranks run -- disparity equal to the oracle chain, cloud NaN mask consistent."""
+    import torch
+    from ros_gpu_stereo_processor_amd import kernels as K, rowsplit as RS, capi
+    from ros_gpu_stereo_processor_amd import dist as D
+    w, h, nd = 480, 130, 48
+    calib = synth.scaled_calibration(w, h)
+    lr, rr, _, _ = synth.raw_pair(w, h, nd, seed=9, calib=calib)
+    maps = []
+    for side in ("left", "right"):
+        m1, m2 = D.build_maps_host(calib[side], w, h)
+        maps += [torch.from_numpy(m1).to(gpu), torch.from_numpy(m2.view(np.int16)).to(gpu)]
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=11, min_disparity=0, num_disparities=nd, texture_threshold=10, uniqueness_ratio=15,
+              disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    Q = oracle.stereo_q(calib["left"]["P"], calib["right"]["P"])
+    y0, y1, d, f32, cloud = RS.rowsplit_frame(torch.from_numpy(lr).to(gpu), torch.from_numpy(rr).to(gpu), maps, capi.BMParams(**kw), 0, 1, 60, 32, Q,
+                                              calib["left"]["P"][2], calib["right"]["P"][2])
+    ml = oracle.init_undistort_rectify_map(calib["left"]["K"], calib["left"]["D"], calib["left"]["R"], calib["left"]["P"], w, h)
+    mr = oracle.init_undistort_rectify_map(calib["right"]["K"], calib["right"]["D"], calib["right"]["R"], calib["right"]["P"], w, h)
+    exp = oracle.filter_speckles(oracle.stereobm(oracle.remap(lr, *ml), oracle.remap(rr, *mr), oracle.bm_params(**kw)), -16, 60, 32)
+    assert (y0, y1) == (0, h) and np.array_equal(d.cpu().numpy(), exp) and (exp != -16).mean() > 0.2
+    assert np.array_equal(f32.cpu().numpy(), oracle.disparity_to_f32(exp, calib["left"]["P"][2], calib["right"]["P"][2]))
+    nan_mask = np.isnan(cloud.cpu().numpy()[..., :4].copy().view(np.float32))[..., 0]
+    assert np.array_equal(nan_mask, exp == -16)
+
+
+@pytest.mark.gpu
+def test_nccl_broadcast_and_halo_exchange_two_devices(gpu):
+    """The two collectives of the multi-GPU modes over RCCL ("nccl" backend): the model broadcast of the frame-sharded mode and the
+    halo exchange + border all-gather of the row-tile split.  Needs two visible devices; the 1-GPU test box skips it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's 8-GPU node runs the N > 1 bench)")
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                          os.path.join(root, "tools", "nccl_selftest.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "nccl selftest ok" in out.stdout
