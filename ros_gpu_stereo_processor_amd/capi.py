@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpuimageproc_hip.so")
+# GIP_LIB_PATH: an alternative build of the same library (A/B experiments: tools/ab_*.sh); default = the in-tree build
+LIB_PATH = os.environ.get("GIP_LIB_PATH") or os.path.join(_HERE, "lib", "libgpuimageproc_hip.so")
 
 # status codes
 OK, ERR_INVALID_ARG, ERR_NOT_INITIALISED, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_EMPTY_SLOT, ERR_IO = range(8)

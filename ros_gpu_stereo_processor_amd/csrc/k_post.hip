@@ -181,8 +181,18 @@ __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, f
 // With one thread per pixel about every second wavefront holds one such lane and stays resident for microseconds (0.19 ms
 // for merge and for sizes on 64 x 1242x375 maps); and thousands of simultaneous global unions build trees as deep as the
 // image is tall.  Lists make the slow path dense; the LDS level makes it short.
-constexpr int SPK_STRIP = 32;        // rows per strip
-constexpr int SPK_CAP = 7168;        // runs per strip the LDS level can hold (else the strip is merged globally)
+#ifndef SPK_STRIP_N
+#define SPK_STRIP_N 8
+#endif
+#ifndef SPK_CAP_N
+#define SPK_CAP_N 1280
+#endif
+// Strip height / LDS capacity are sized so that a strip workgroup needs 10 KB of LDS.  With 32-row strips (57 KB) the kernel took 642 us
+// next to the matcher of another batch against 29 us alone: the matcher keeps every CU's 160 KB full with 20 KB workgroups that are
+// replaced one at a time, so a 57 KB request starves.  At 10 KB it takes 99 us co-scheduled (the ~3x every small kernel stretches by);
+// the global merge of the strip seams (k_spk_cross) grows from 17 to 31 us, throughput is unchanged (profiles/r02_stretch.txt).
+constexpr int SPK_STRIP = SPK_STRIP_N;        // rows per strip
+constexpr int SPK_CAP = SPK_CAP_N;        // runs per strip the LDS level can hold (else the strip is merged globally)
 constexpr int SPK_TPB = 256;
 
 __device__ __forceinline__ int uf_find(int* nd, int i)
