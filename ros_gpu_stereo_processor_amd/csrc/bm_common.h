@@ -16,10 +16,12 @@ struct BmArgs {
     int TC;              // generic kernel: columns per tile
     int16_t* disp;
     size_t dpitch;       // elements
-    int32_t* cost;       // may be null
+    int32_t* cost;       // may be null; min-SAD plane (int32, or uint16 when cost16 is set)
     size_t cpitch;       // elements
+    int cost16;          // column-sum matcher only: the plane is uint16 (its window sums are < 65535 by construction)
     size_t img_bs, disp_bs, cost_bs;  // batch strides in bytes
     int filtered;
+    int ntiles, nchunks, nimg;   // column-sum matcher: extent of its (tile, row chunk, image) work space (set by the launcher)
 };
 
 // Host-side launch context of the dominant kernel (the SAD matcher); every field may be null.  Travels as an argument from

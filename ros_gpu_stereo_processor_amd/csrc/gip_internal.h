@@ -59,7 +59,10 @@ int gip_validate_bm_params(const gip_bm_params* p, int w, int h);
 struct BmLaunchCtx;   // bm_common.h
 int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride, size_t cost_bstride, gip_stream stream,
-                      bool skip_fill, const BmLaunchCtx* ctx);
+                      bool skip_fill, const BmLaunchCtx* ctx, int* cost_u16);
+// gipk_bm_finalize on a uint16 min-SAD plane (cost_pitch / cost_bstride in bytes)
+int gip_bm_finalize_impl(int16_t* disp, size_t disp_pitch, const void* cost, size_t cost_pitch, int w, int h, const gip_bm_params* p, int batch, size_t disp_bstride,
+                         size_t cost_bstride, gip_stream stream, bool cost_u16);
 // gipk_stereobm with a launch context for the matcher (events around it, optional stream of its own).  left == right == nullptr
 // means the caller has already written the PREFILTERED planes into the scratch (gip_stereobm_planes tells where): the fused
 // rectify + XSOBEL front end of gip_batch_run does that.

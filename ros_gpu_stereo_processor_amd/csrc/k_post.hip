@@ -24,7 +24,8 @@ constexpr int TPB = 256;
 // One workgroup per image row.  disp2/cost2 of cv::validateDisparity become one 64-bit key per target column
 // (cost << 32 | x << 16 | d) reduced with an LDS atomic min: lowest cost wins, ties go to the smallest x --
 // exactly the strict '>' replacement rule of the sequential scan.
-__global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const int32_t* cost, size_t cpitch, int w, int h, int mindisp, int ndisp,
+template <class CT>
+__global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const CT* cost, size_t cpitch, int w, int h, int mindisp, int ndisp,
                               int disp12, int roi_x, int roi_y, int roi_w, int roi_h, int wr0, int wr1, size_t dbs, size_t cbs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -37,7 +38,7 @@ __global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const int32_t* cost,
         return;
     }
     if (disp12 >= 0) {
-        const int32_t* cptr = (const int32_t*)((const uint8_t*)cost + blockIdx.z * cbs) + (size_t)y * cpitch;
+        const CT* cptr = (const CT*)((const uint8_t*)cost + blockIdx.z * cbs) + (size_t)y * cpitch;
         const int minD = mindisp, maxD = mindisp + ndisp;
         const int minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (minD < 0 ? minD : 0);
         const int maxdiff = disp12 * 16;
@@ -77,8 +78,8 @@ __global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const int32_t* cost,
 
 // Same, for rows of at most 256 * NI pixels: every thread keeps its NI pixels in registers across the three phases, so the
 // disparity row is read once and only the pixels that change are written back.
-template <int NI>
-__global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpitch, const int32_t* cost, size_t cpitch, int w, int h, int mindisp,
+template <int NI, class CT>
+__global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpitch, const CT* cost, size_t cpitch, int w, int h, int mindisp,
                                                         int ndisp, int disp12, int roi_x, int roi_y, int roi_w, int roi_h, int wr0, int wr1, size_t dbs,
                                                         size_t cbs)
 {
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpi
 #pragma unroll
     for (int i = 0; i < NI; i++) kill[i] = false;
     if (disp12 >= 0) {
-        const int32_t* cptr = (const int32_t*)((const uint8_t*)cost + blockIdx.z * cbs) + (size_t)y * cpitch;
+        const CT* cptr = (const CT*)((const uint8_t*)cost + blockIdx.z * cbs) + (size_t)y * cpitch;
         const int minD = mindisp, maxD = mindisp + ndisp;
         const int minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (minD < 0 ? minD : 0);
         const int maxdiff = disp12 * 16;
@@ -721,25 +722,43 @@ extern "C" {
 int gipk_bm_finalize(int16_t* disp, size_t disp_pitch, const int32_t* cost, size_t cost_pitch, int w, int h, const gip_bm_params* p, int batch,
                      size_t disp_bstride, size_t cost_bstride, gip_stream stream)
 {
-    GIPK_ARGCHECK(disp && p && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
-    GIPK_ARGCHECK(p->disp12_max_diff < 0 || (cost && cost_pitch % 4 == 0));
-    if (w > 16384) return GIP_ERR_UNSUPPORTED;
+    return gip_bm_finalize_impl(disp, disp_pitch, cost, cost_pitch, w, h, p, batch, disp_bstride, cost_bstride, stream, false);
+}
+
+}  // extern "C"
+
+template <class CT>
+static int finalize_launch(int16_t* disp, size_t disp_pitch, const CT* cost, size_t cost_pitch, int w, int h, const gip_bm_params* p, int batch, size_t disp_bstride,
+                           size_t cost_bstride, gip_stream stream)
+{
     const GipBmGeom g = gip_bm_geom(w, h, p);
     size_t sh = p->disp12_max_diff >= 0 ? (size_t)w * 8 : 16;
-    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_finalize<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     int rx = g.roi_x, ry = g.roi_y, rw = g.roi_w, rh = g.roi_h;
     if (g.degenerate) { rx = ry = rw = rh = 0; }
-#define GIP_FINALIZE_ARGS disp, disp_pitch / 2, cost, cost ? cost_pitch / 4 : 0, w, h, p->min_disparity, p->num_disparities, g.degenerate ? -1 : p->disp12_max_diff, rx, ry, \
+#define GIP_FINALIZE_ARGS disp, disp_pitch / 2, cost, cost ? cost_pitch / sizeof(CT) : 0, w, h, p->min_disparity, p->num_disparities, g.degenerate ? -1 : p->disp12_max_diff, rx, ry, \
                           rw, rh, g.lofs, g.lofs + g.width1, disp_bstride, cost_bstride
     const dim3 grid(h, 1, batch);
-    if (w <= 2 * TPB) hipLaunchKernelGGL(k_bm_finalize_r<2>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
-    else if (w <= 5 * TPB) hipLaunchKernelGGL(k_bm_finalize_r<5>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
-    else if (w <= 8 * TPB) hipLaunchKernelGGL(k_bm_finalize_r<8>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
-    else hipLaunchKernelGGL(k_bm_finalize, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    if (w <= 2 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<2, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    else if (w <= 5 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<5, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    else if (w <= 8 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<8, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    else hipLaunchKernelGGL(k_bm_finalize<CT>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
 #undef GIP_FINALIZE_ARGS
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
+
+int gip_bm_finalize_impl(int16_t* disp, size_t disp_pitch, const void* cost, size_t cost_pitch, int w, int h, const gip_bm_params* p, int batch, size_t disp_bstride,
+                         size_t cost_bstride, gip_stream stream, bool cost_u16)
+{
+    GIPK_ARGCHECK(disp && p && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
+    GIPK_ARGCHECK(p->disp12_max_diff < 0 || (cost && cost_pitch % 4 == 0));
+    if (w > 16384) return GIP_ERR_UNSUPPORTED;
+    if (cost_u16) return finalize_launch<uint16_t>(disp, disp_pitch, (const uint16_t*)cost, cost_pitch, w, h, p, batch, disp_bstride, cost_bstride, stream);
+    return finalize_launch<int32_t>(disp, disp_pitch, (const int32_t*)cost, cost_pitch, w, h, p, batch, disp_bstride, cost_bstride, stream);
+}
+
+extern "C" {
 
 int gipk_disparity_to_f32(const int16_t* disp, size_t disp_pitch, float* dst, size_t dst_pitch, int w, int h, double cx_l, double cx_r, int batch,
                           size_t disp_bstride, size_t dst_bstride, gip_stream stream)
@@ -952,9 +971,12 @@ int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
         if (rc != GIP_OK) return rc;
     }
     const bool lr = p->disp12_max_diff >= 0;
-    rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true, ctx);
+    // min-SAD plane for the L/R check: uint16 when the column-sum matcher runs (its sums are < 65535), else int32; the byte pitch is
+    // the same (rows of 4 * w bytes, half used by a uint16 plane), so the scratch layout does not depend on the choice
+    int cost_u16 = 1;
+    rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true, ctx, &cost_u16);
     if (rc != GIP_OK) return rc;
-    rc = gipk_bm_finalize(disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, w, h, p, batch, disp_bstride, (size_t)w * h * 4, stream);
+    rc = gip_bm_finalize_impl(disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, w, h, p, batch, disp_bstride, (size_t)w * h * 4, stream, cost_u16 != 0);
     if (rc != GIP_OK) return rc;
     if (p->speckle_range >= 0 && p->speckle_window_size > 0)
         rc = gipk_filter_speckles(disp, disp_pitch, w, h, (p->min_disparity - 1) * 16, p->speckle_window_size, p->speckle_range, spk,

@@ -442,16 +442,20 @@ extern "C" int gipk_bm_match(const uint8_t* left, const uint8_t* right, size_t p
                              size_t disp_pitch, int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride,
                              size_t cost_bstride, gip_stream stream)
 {
-    return gip_bm_match_impl(left, right, pitch, w, h, p, disp, disp_pitch, cost, cost_pitch, batch, img_bstride, disp_bstride, cost_bstride, stream, false, nullptr);
+    return gip_bm_match_impl(left, right, pitch, w, h, p, disp, disp_pitch, cost, cost_pitch, batch, img_bstride, disp_bstride, cost_bstride, stream, false, nullptr, nullptr);
 }
 
 // skip_fill: the caller runs gipk_bm_finalize afterwards, which blanks every pixel the matcher does not write
 int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       int32_t* cost, size_t cost_pitch, int batch, size_t img_bstride, size_t disp_bstride, size_t cost_bstride, gip_stream stream,
-                      bool skip_fill, const BmLaunchCtx* ctx)
+                      bool skip_fill, const BmLaunchCtx* ctx, int* cost_u16)
 {
+    // cost_u16: in = the caller accepts a uint16 min-SAD plane (cost_pitch / cost_bstride then describe 2-byte elements), out = whether
+    // the matcher wrote one (only the column-sum matcher does; the other kernels keep int32)
+    const bool want16 = cost_u16 && *cost_u16;
+    if (cost_u16) *cost_u16 = 0;
     if (!left || !right || !disp || w <= 0 || h <= 0 || batch <= 0) return GIP_ERR_INVALID_ARG;
-    if (disp_pitch % 2 || (cost && cost_pitch % 4)) return GIP_ERR_INVALID_ARG;
+    if (disp_pitch % 2 || (cost && cost_pitch % 4)) return GIP_ERR_INVALID_ARG;   // (a uint16 plane is addressed with the same 4-byte aligned byte pitch)
     int rc = gip_validate_bm_params(p, w, h);
     if (rc != GIP_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -472,7 +476,8 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     a.ndisp = g.ndisp; a.mindisp = g.mindisp; a.wsz2 = g.wsz2; a.lofs = g.lofs; a.rofs = g.rofs; a.width1 = g.width1;
     a.ftzero = p->prefilter_cap; a.tex_thr = p->texture_threshold; a.uniq = p->uniqueness_ratio;
     a.row0 = g.roi_y; a.row1 = g.roi_y + g.roi_h;
-    a.disp = disp; a.dpitch = disp_pitch / 2; a.cost = cost; a.cpitch = cost ? cost_pitch / 4 : 0;
+    a.disp = disp; a.dpitch = disp_pitch / 2; a.cost = cost; a.cpitch = cost ? cost_pitch / 4 : 0; a.cost16 = 0;
+    a.ntiles = a.nchunks = a.nimg = 0;
     a.img_bs = img_bstride; a.disp_bs = disp_bstride; a.cost_bs = cost_bstride; a.filtered = g.filtered;
     a.cbeg = a.cend = a.nleft = a.nright = 0; a.TC = 64;
     if (wide) {
@@ -532,6 +537,11 @@ int gip_bm_match_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     a.cbeg = 0; a.cend = g.width1;
     if (gip_bm_c4_can(a)) {
         bool c4_done = false;
+        if (want16 && cost) {   // same buffer, 2-byte elements: pitch in elements doubles for the same byte pitch
+            a.cost16 = 1;
+            a.cpitch = cost_pitch / 2;
+            *cost_u16 = 1;
+        }
         rc = gip_bm_c4_launch(a, batch, st, ctx, &c4_done);
         if (rc != GIP_OK) return rc;
         return c4_done ? GIP_OK : GIP_ERR_UNSUPPORTED;

@@ -50,6 +50,9 @@
 #ifndef C4_B128     /* 1: park two groups per 16-byte LDS store */
 #define C4_B128 1
 #endif
+#ifndef C4_XCD_MAP  /* 1: contiguous ranges of tiles per XCD (L2 locality) instead of the natural blockIdx order */
+#define C4_XCD_MAP 1
+#endif
 #ifndef C4_NOSYNC   /* 1: one-wave workgroups order their LDS traffic by program order only (no s_waitcnt drain) */
 #define C4_NOSYNC 1
 #endif
@@ -253,7 +256,7 @@ __device__ __forceinline__ void hsum_pf(u32 T, u32 P1, u32 P2, u32 P3, u32& H0, 
 //
 // PF: prefix form (interior tile) or column form (border tile); uniform per workgroup.
 template <int NG, int R, int NW, bool PF>
-__device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb)
+__device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb, int img)
 {
     constexpr int K = (R + 3) / 4;
     constexpr int NRING = 2 * R + 1;
@@ -274,10 +277,10 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     const int tid = threadIdx.x, wave = tid >> 6;
     const int lane = tid & 63, t = lane & 15, sl = lane >> 4, s = 4 * wave + sl;
 
-    const uint8_t* Lb = a.L + blockIdx.z * a.img_bs;
-    const uint8_t* Rb = a.R + blockIdx.z * a.img_bs;
-    int16_t* disp = (int16_t*)((uint8_t*)a.disp + blockIdx.z * a.disp_bs);
-    int32_t* cost = a.cost ? (int32_t*)((uint8_t*)a.cost + blockIdx.z * a.cost_bs) : nullptr;
+    const uint8_t* Lb = a.L + (size_t)img * a.img_bs;
+    const uint8_t* Rb = a.R + (size_t)img * a.img_bs;
+    int16_t* disp = (int16_t*)((uint8_t*)a.disp + (size_t)img * a.disp_bs);
+    int32_t* cost = a.cost ? (int32_t*)((uint8_t*)a.cost + (size_t)img * a.cost_bs) : nullptr;
 
     // ---- row staging: aligned dword loads + funnel shift, clamped to the row's dword range (pitch % 4 == 0)
     const int lcol0 = a.lofs + c0;   // absolute column of L ring byte 0
@@ -610,7 +613,10 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         }
         if (writer) {
             disp[(size_t)y * a.dpitch + a.lofs + c_out] = (int16_t)d_out;
-            if (cost) cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
+            if (cost) {
+                if (a.cost16) ((uint16_t*)cost)[(size_t)y * a.cpitch + a.lofs + c_out] = (uint16_t)minsad;
+                else cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
+            }
         }
         if (!C4_PIPE && !(C4_ABLATE & 1)) sub_regs(read_row(y - R));
     }
@@ -621,17 +627,36 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 {
     constexpr int K = (R + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-    const int c0 = a.cbeg - 4 * K + blockIdx.x * (64 - 8 * K);   // relative column of lane t=0, q=0
-    const int ya = a.row0 + blockIdx.y * a.rows_per_chunk;
+    // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so with the natural order
+    // neighbouring tiles -- which share 2/3 of their right-image window and all of their rows -- would land on 8 different L2s.
+    // Instead XCD x (= workgroup id mod 8) walks the CONTIGUOUS range [x * M, (x + 1) * M) of the (image, chunk, tile) space, tile
+    // fastest: the overlap of adjacent tiles and the warm-up rows of adjacent chunks are then L2 hits (FETCH_SIZE per launch, KITTI
+    // workload: profiles/traffic.json).  Placement is a speed matter only; nothing depends on it.
+    int tile, chunk, img;
+#if C4_XCD_MAP
+    {
+        const int nwg = a.ntiles * a.nchunks * a.nimg, M = (nwg + 7) >> 3;
+        const int v = (int)(blockIdx.x & 7u) * M + (int)(blockIdx.x >> 3);
+        if (v >= nwg) return;
+        tile = v % a.ntiles;
+        const int rest = v / a.ntiles;
+        chunk = rest % a.nchunks;
+        img = rest / a.nchunks;
+    }
+#else
+    tile = blockIdx.x; chunk = blockIdx.y; img = blockIdx.z;
+#endif
+    const int c0 = a.cbeg - 4 * K + tile * (64 - 8 * K);   // relative column of lane t=0, q=0
+    const int ya = a.row0 + chunk * a.rows_per_chunk;
     const int yb = min(ya + a.rows_per_chunk, a.row1);
     if (ya >= yb) return;
     // interior tile: no column of the tile is touched by the right-image clamp (rofs + clamp(cc, -rofs, w - ndisp - rofs) + d)
     const bool interior = c0 >= -a.rofs && c0 + 63 <= a.w - a.ndisp - a.rofs;
 #ifdef C4_NO_PF
-    bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb);
+    bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb, img);
 #else
-    if (interior) bm_c4_tile<NG, R, NW, true>(a, smem_raw, c0, ya, yb);
-    else bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb);
+    if (interior) bm_c4_tile<NG, R, NW, true>(a, smem_raw, c0, ya, yb, img);
+    else bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb, img);
 #endif
 }
 
@@ -677,6 +702,12 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
     BmArgs b = a;
     b.rows_per_chunk = (nrows + nch - 1) / nch;
     nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;
+    b.ntiles = ntiles; b.nchunks = nch; b.nimg = batch;
+#if C4_XCD_MAP
+    const dim3 grid((unsigned)(8 * (((size_t)ntiles * nch * batch + 7) / 8)));
+#else
+    const dim3 grid(ntiles, nch, batch);
+#endif
     if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     // the matcher may run on a stream of its own (BmLaunchCtx::matcher_stream), fenced by events on both sides
     hipStream_t ks = st;
@@ -687,7 +718,7 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
         GIP_HIP_CHECK(hipStreamWaitEvent(ks, ctx->fork, 0));
     }
     if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, ks));
-    hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), dim3(ntiles, nch, batch), dim3(64 * NW), sh, ks, b);
+    hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), grid, dim3(64 * NW), sh, ks, b);
     GIP_LAUNCH_CHECK();
     if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, ks));
     if (forked) {
