@@ -50,6 +50,9 @@
 #ifndef C4_B128     /* 1: park two groups per 16-byte LDS store */
 #define C4_B128 1
 #endif
+#ifndef C4_OCT      /* 1: winner-take-all and uniqueness count per 8-disparity group (pairs of v_mqsad groups) when NG is even */
+#define C4_OCT 1
+#endif
 #ifndef C4_XCD_MAP  /* 1: contiguous ranges of tiles per XCD (L2 locality) instead of the natural blockIdx order */
 #define C4_XCD_MAP 1
 #endif
@@ -269,6 +272,12 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     constexpr int CSPB = 2 * NDISP + 16;        // bytes per column of the cost slice
     constexpr int NLD = (RWD + NT - 1) / NT;    // right-row dwords each thread stages per row
     constexpr int QPW = 4 / NW;                 // pixel columns q finalised per wave
+    // Winner-take-all granularity: the key of a column is (min cost << 8 | group), the group's costs are re-read from the LDS cost slice
+    // at finalisation.  With 8-disparity groups ("octets" = two v_mqsad groups, which are parked together anyway) the per-group work --
+    // horizontal min, key, running min, uniqueness compare-and-count -- halves; finalisation reads three octets instead of three quads.
+    // NG must be even so that no octet is split between two lanes (the count would see it twice).
+    constexpr bool OCT = (C4_OCT != 0) && (C4_B128 != 0) && (NG % 2 == 0);
+    constexpr int NGK = OCT ? NG / 2 : NG;      // key groups per lane
     u32* ring = (u32*)smem_raw;
     uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
     u32* xbest = (u32*)(cs + (size_t)64 * CSPB);   // [NW][16][4] winner keys of each wave   (NW > 1 only)
@@ -459,6 +468,13 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             gmin[q][g] = gm;
             best[q] = umin(best[q], (gm << 8) | (u32)(NG * s + g));
         };
+        auto wta8 = [&](auto qv, int o, P2 Ha, P2 Hb) {
+            constexpr int q = decltype(qv)::value;
+            u32 m = pk_min_u16(pk_min_u16(Ha.lo, Ha.hi), pk_min_u16(Hb.lo, Hb.hi));
+            u32 gm = umin(m & 0xFFFFu, m >> 16);
+            gmin[q][o] = gm;
+            best[q] = umin(best[q], (gm << 8) | (u32)(NGK * s + o));
+        };
         auto park = [&](auto qv, int g, P2 H0, P2 H1, bool two) {
             constexpr int q = decltype(qv)::value;
             if constexpr (C4_ABLATE & 4) return;
@@ -493,8 +509,11 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             if (two) window_sums(g + 1, Hb);
             static_for<0, 4>([&](auto qv) {
                 constexpr int q = decltype(qv)::value;
-                wta(qv, g, Ha[q]);
-                if (two) wta(qv, g + 1, Hb[q]);
+                if constexpr (OCT) wta8(qv, g / 2, Ha[q], Hb[q]);
+                else {
+                    wta(qv, g, Ha[q]);
+                    if (two) wta(qv, g + 1, Hb[q]);
+                }
                 park(qv, g, Ha[q], Hb[q], two);
             });
             if (!C4_B128) g--;    // one group per step
@@ -537,7 +556,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 const u32 ms = best[q] >> 8;
                 const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
 #pragma unroll
-                for (int g = 0; g < NG; g++) cnt[q] += (gmin[q][g] <= thr) ? 1u : 0u;
+                for (int g = 0; g < NGK; g++) cnt[q] += (gmin[q][g] <= thr) ? 1u : 0u;
                 if constexpr (!(C4_ABLATE & 8)) {
                     cnt[q] += (u32)__shfl_xor((int)cnt[q], 16);
                     cnt[q] += (u32)__shfl_xor((int)cnt[q], 32);
@@ -565,28 +584,56 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             // The winner's group and its two neighbours in ONE LDS round trip: 12 costs as six packed dwords D0..D5, entry
             // 4 + k is the winner (k = first minimum inside its group), entries 3 + k / 5 + k its sub-pixel neighbours.
             // Groups beyond either end of the range read as 0xFFFF (never <= a threshold; a real cost is < 0xFFFF).
-            constexpr int NGT = NS * NG;
-            const bool has_m = gstar > 0, has_p = gstar + 1 < NGT;
-            const uint2 gm_ = *(const uint2*)(csrow_r + (has_m ? gstar - 1 : gstar) * 8);
-            const uint2 g0_ = *(const uint2*)(csrow_r + gstar * 8);
-            const uint2 gp_ = *(const uint2*)(csrow_r + (has_p ? gstar + 1 : gstar) * 8);
-            const u32 D0 = has_m ? gm_.x : ~0u, D1 = has_m ? gm_.y : ~0u, D2 = g0_.x, D3 = g0_.y, D4 = has_p ? gp_.x : ~0u, D5 = has_p ? gp_.y : ~0u;
             const u32 ms = (u32)minsad;
+            u32 D0, D1, D2, D3, D4, D5;
+            int g4;                                   // 4-disparity group that holds the winner
+            // octet mode: the costs of the two octets' halves that lie outside (D0..D5), and the minima of the three octets read
+            u32 other = ~0u, om_m = ~0u, om_0 = ~0u, om_p = ~0u;
+            if constexpr (OCT) {
+                constexpr int NOT = NS * NGK;
+                const bool has_m = gstar > 0, has_p = gstar + 1 < NOT;
+                uint4 A = *(const uint4*)(csrow_r + (has_m ? gstar - 1 : gstar) * 16);
+                const uint4 B = *(const uint4*)(csrow_r + gstar * 16);
+                uint4 Cn = *(const uint4*)(csrow_r + (has_p ? gstar + 1 : gstar) * 16);
+                if (!has_m) A = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (!has_p) Cn = make_uint4(~0u, ~0u, ~0u, ~0u);
+                const u32 mlo = pk_min_u16(B.x, B.y);
+                const bool low = umin(mlo & 0xFFFFu, mlo >> 16) == ms;     // the first minimum lies in the octet's lower quad
+                g4 = 2 * gstar + (low ? 0 : 1);
+                D0 = low ? A.z : B.x; D1 = low ? A.w : B.y;
+                D2 = low ? B.x : B.z; D3 = low ? B.y : B.w;
+                D4 = low ? B.z : Cn.x; D5 = low ? B.w : Cn.y;
+                // the 12 costs of the three octets that are not in D0..D5 lie entirely outside [mind - 1, mind + 1]
+                other = pk_min_u16(pk_min_u16(pk_min_u16(A.x, A.y), pk_min_u16(Cn.z, Cn.w)), pk_min_u16(low ? Cn.x : A.z, low ? Cn.y : A.w));
+                om_m = pk_min_u16(pk_min_u16(A.x, A.y), pk_min_u16(A.z, A.w));
+                om_0 = pk_min_u16(mlo, pk_min_u16(B.z, B.w));
+                om_p = pk_min_u16(pk_min_u16(Cn.x, Cn.y), pk_min_u16(Cn.z, Cn.w));
+            } else {
+                constexpr int NGT = NS * NG;
+                const bool has_m = gstar > 0, has_p = gstar + 1 < NGT;
+                const uint2 gm_ = *(const uint2*)(csrow_r + (has_m ? gstar - 1 : gstar) * 8);
+                const uint2 g0_ = *(const uint2*)(csrow_r + gstar * 8);
+                const uint2 gp_ = *(const uint2*)(csrow_r + (has_p ? gstar + 1 : gstar) * 8);
+                D0 = has_m ? gm_.x : ~0u; D1 = has_m ? gm_.y : ~0u; D2 = g0_.x; D3 = g0_.y; D4 = has_p ? gp_.x : ~0u; D5 = has_p ? gp_.y : ~0u;
+                g4 = gstar;
+            }
             const u32 h1 = D1 >> 16, h2 = D2 & 0xFFFFu, h3 = D2 >> 16, h4 = D3 & 0xFFFFu, h5 = D3 >> 16, h6 = D4 & 0xFFFFu;
             const int k = (h2 == ms) ? 0 : (h3 == ms) ? 1 : (h4 == ms) ? 2 : 3;   // first minimum
-            const int mind = 4 * gstar + k;
+            const int mind = 4 * g4 + k;
             bool ok = tsum >= a.tex_thr;
             if (a.uniq > 0) {
                 // exact part of the uniqueness test on the 12 costs, packed: "some u16 of x is <= thr"  <=>  pk_min(x, T1) != T1
                 // with T1 = thr + 1 in both halves
                 const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
                 const u32 t1 = umin(thr + 1u, 0xFFFFu), T1 = t1 | (t1 << 16);
-                const int touch_le = (pk_min_u16(pk_min_u16(D0, D1), T1) != T1) + (pk_min_u16(pk_min_u16(D2, D3), T1) != T1) +
-                                     (pk_min_u16(pk_min_u16(D4, D5), T1) != T1);
+                // key groups among the three read whose minimum is <= thr (what the count over ALL key groups must not exceed)
+                int touch_le;
+                if constexpr (OCT) touch_le = (pk_min_u16(om_m, T1) != T1) + (pk_min_u16(om_0, T1) != T1) + (pk_min_u16(om_p, T1) != T1);
+                else touch_le = (pk_min_u16(pk_min_u16(D0, D1), T1) != T1) + (pk_min_u16(pk_min_u16(D2, D3), T1) != T1) + (pk_min_u16(pk_min_u16(D4, D5), T1) != T1);
                 // blank entries 3+k .. 5+k (the winner and its neighbours): a 48-bit window sliding over (D1, D2, D3, D4)
                 const u64 wlo = 0xFFFFFFFFFFFF0000ull << (16 * k), whi = 0x0000FFFFFFFFFFFFull >> (16 * (3 - k));
                 const u32 E1 = D1 | (u32)wlo, E2 = D2 | (u32)(wlo >> 32), E3 = D3 | (u32)whi, E4 = D4 | (u32)(whi >> 32);
-                const u32 rest = pk_min_u16(pk_min_u16(pk_min_u16(D0, E1), pk_min_u16(E2, E3)), pk_min_u16(E4, D5));
+                const u32 rest = pk_min_u16(pk_min_u16(pk_min_u16(pk_min_u16(D0, E1), pk_min_u16(E2, E3)), pk_min_u16(E4, D5)), other);
                 const bool viol = pk_min_u16(rest, T1) != T1;
                 // a group that does not touch the winner lies entirely outside [mind-1, mind+1]
                 ok = ok && !viol && (ngle <= touch_le);
