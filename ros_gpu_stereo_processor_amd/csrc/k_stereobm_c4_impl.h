@@ -53,6 +53,9 @@
 #ifndef C4_OCT      /* 1: winner-take-all and uniqueness count per 8-disparity group (pairs of v_mqsad groups) when NG is even */
 #define C4_OCT 1
 #endif
+#ifndef C4_ROTFIN   /* 1: multi-wave workgroups: ONE wave (rotating per row) finalises all 64 pixels of the row with every lane active */
+#define C4_ROTFIN 1
+#endif
 #ifndef C4_XCD_MAP  /* 1: contiguous ranges of tiles per XCD (L2 locality) instead of the natural blockIdx order */
 #define C4_XCD_MAP 1
 #endif
@@ -428,10 +431,14 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     for (int yy = ya - R; yy < ya + R; yy++) add_regs(read_row(yy));
     prefetch(ya + R);
 
-    // the pixel this lane finalises: column 4t + qf.  One wave: qf = lane / 16.  NW waves: wave w takes q in [w*QPW, (w+1)*QPW),
-    // its lanes with lane / 16 >= QPW have no pixel.
-    const bool fin = sl < QPW;
-    const int qf = (wave * QPW + sl) & 3;
+    // the pixel this lane finalises: column 4t + qf.  One wave: qf = lane / 16.  NW waves: every wave ends up with the merged keys,
+    // counts and texture sums of all four columns of its lanes, so ONE wave can finalise the whole row (qf = lane / 16, every lane
+    // active); the waves take turns row by row (ROT).  The other waves skip the block and wait at the next row's first barrier -- no
+    // extra barrier, the same critical path, but three quarters of the finalisation's issue slots are left to other workgroups
+    // (without ROT wave w takes q in [w*QPW, (w+1)*QPW) and its lanes with lane / 16 >= QPW idle through the whole block).
+    constexpr bool ROT = (C4_ROTFIN != 0) && NW > 1;
+    const bool fin = ROT ? true : (sl < QPW);
+    const int qf = ROT ? sl : ((wave * QPW + sl) & 3);
     const int my_col = 4 * t + qf;
     const int c_out = c0 + my_col;
     const bool writer = fin && (t >= K) && (t <= 15 - K) && (c_out >= a.cbeg) && (c_out < a.cend);
@@ -574,6 +581,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             }
         }
         // ---- finalise pixel (column 4t+qf) in this lane
+        if (!ROT || wave == ((y - ya) & (NW - 1))) {
         const u32 key = qf == 0 ? best[0] : qf == 1 ? best[1] : qf == 2 ? best[2] : best[3];
         const int tsum = (int)(qf == 0 ? tsum_q[0] : qf == 1 ? tsum_q[1] : qf == 2 ? tsum_q[2] : tsum_q[3]);
         const int ngle = (int)(qf == 0 ? cnt[0] : qf == 1 ? cnt[1] : qf == 2 ? cnt[2] : cnt[3]);
@@ -665,6 +673,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 else cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
             }
         }
+        }   // finalising wave
         if (!C4_PIPE && !(C4_ABLATE & 1)) sub_regs(read_row(y - R));
     }
 }
