@@ -172,6 +172,9 @@ class GpuStereoProcessor
     void setPreFilterCap(int v) { ck(gip_set_pre_filter_cap(h_, v)); }
     void setUniquenessRatio(int v) { ck(gip_set_uniqueness_ratio(h_, v)); }
     void setDisp12MaxDiff(int v) { ck(gip_set_disp12_max_diff(h_, v)); }
+    // the whole StereoBM parameter block at once (validated like cv::StereoBM::compute does)
+    void setParams(const gip_bm_params &p) { ck(gip_set_params(h_, &p)); }
+    gip_bm_params getParams() const { gip_bm_params p{}; gip_get_params(h_, &p); return p; }
     // the imageCb schedule (StereoProcessor.cpp:157-298) in one call
     void processPair(const Mat &l_raw, const Mat &r_raw, const std::string &encoding, uint32_t connected_topics)
     {

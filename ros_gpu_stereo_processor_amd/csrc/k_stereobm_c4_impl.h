@@ -799,15 +799,27 @@ int dispatch_ndisp(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx
     case 80: return launch_c4<5, R, 1>(a, batch, st, ctx);
     case 96: return launch_c4<6, R, 1>(a, batch, st, ctx);
     case 112: return launch_c4<7, R, 1>(a, batch, st, ctx);
+#ifdef C4_CFG_128
+    case 128: return launch_c4<C4_CFG_128>(a, batch, st, ctx);
+#else
     case 128: return launch_c4<8, R, 1>(a, batch, st, ctx);
+#endif
     case 144: return launch_c4<9, R, 1>(a, batch, st, ctx);
     case 160: return launch_c4<5, R, 2>(a, batch, st, ctx);
     case 176: return launch_c4<11, R, 1>(a, batch, st, ctx);
+#ifdef C4_CFG_192
+    case 192: return launch_c4<C4_CFG_192>(a, batch, st, ctx);
+#else
     case 192: return launch_c4<6, R, 2>(a, batch, st, ctx);
+#endif
     case 208: return launch_c4<13, R, 1>(a, batch, st, ctx);
     case 224: return launch_c4<7, R, 2>(a, batch, st, ctx);
     case 240: return launch_c4<15, R, 1>(a, batch, st, ctx);
+#ifdef C4_CFG_256
+    case 256: return launch_c4<C4_CFG_256>(a, batch, st, ctx);
+#else
     case 256: return launch_c4<4, R, 4>(a, batch, st, ctx);
+#endif
     default: *handled = false; return GIP_OK;
     }
 }

@@ -8,7 +8,13 @@
 #include <iostream>
 #include <string>
 
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
 #include "gpuimageproc/StereoProcessor.hpp"
+#include "gpuimageproc/StreamingStereo.hpp"
 
 using namespace gpuimageproc;
 
@@ -109,6 +115,47 @@ int main(int argc, char **argv)
         write_raw(dir + "/out_disp16.bin", d16);
         write_raw(dir + "/out_disp32.bin", disp32);
         write_raw(dir + "/out_cloud.bin", cloud);
+    }
+    // The pipelined host link from C++: the same pair through the streaming API (3 batches in flight) and through TWO handles dealt
+    // round-robin (MultiDeviceStereo: one handle per device on an 8-GPU node, two handles on one device here) must deliver, in
+    // submission order, exactly what the synchronous imageCb schedule produced above.
+    {
+        Mat l = read_raw(dir + "/left_raw.bin", 480, 752, GIP_8UC1), r = read_raw(dir + "/right_raw.bin", 480, 752, GIP_8UC1);
+        std::ifstream f32(dir + "/out_disp32.bin", std::ios::binary), fc(dir + "/out_cloud.bin", std::ios::binary);
+        std::vector<float> exp32((size_t)480 * 752);
+        std::vector<unsigned char> expc((size_t)480 * 752 * 32);
+        f32.read((char *)exp32.data(), (std::streamsize)(exp32.size() * 4));
+        fc.read((char *)expc.data(), (std::streamsize)expc.size());
+        gip_camera_info li, ri;
+        char name[64];
+        CHECK(gip_read_calibration((dir + "/left.yaml").c_str(), &li, name, sizeof name) == GIP_OK);
+        CHECK(gip_read_calibration((dir + "/right.yaml").c_str(), &ri, name, sizeof name) == GIP_OK);
+        gip_bm_params p{};
+        p.prefilter_type = GIP_PREFILTER_XSOBEL; p.prefilter_size = 5; p.prefilter_cap = 31; p.block_size = 15; p.min_disparity = 0; p.num_disparities = 64;
+        p.texture_threshold = 10; p.uniqueness_ratio = 0; p.disp12_max_diff = 0;
+        std::mutex mu;
+        std::vector<uint64_t> order[2];
+        std::atomic<int> bad{0};
+        const uint32_t outputs = GIP_TOPIC_DISPARITY | GIP_TOPIC_POINTCLOUD;
+        MultiDeviceStereo multi(2, li, ri, p, 100, 2.0, 752, 480, "mono8", outputs, [&](int slot, const gip_streamer_result &res) {
+            if (std::memcmp(res.disparity_f32, exp32.data(), exp32.size() * 4) != 0) bad++;
+            if (std::memcmp(res.pointcloud, expc.data(), expc.size()) != 0) bad++;
+            if (res.header.seq != 100 + 2 * res.seq + (uint32_t)slot) bad++;          // handle `slot` sees frames slot, slot + 2, ...
+            std::lock_guard<std::mutex> g(mu);
+            order[slot].push_back(res.seq);
+        });
+        CHECK(multi.size() == 2);
+        const int nframes = 9;
+        for (int i = 0; i < nframes; i++) {
+            gip_header hdr{};
+            hdr.seq = 100 + i;
+            multi.imageCb((uint64_t)i, l, r, hdr);
+        }
+        multi.flush();
+        CHECK(bad == 0);
+        CHECK(order[0].size() == 5 && order[1].size() == 4);
+        for (int s2 = 0; s2 < 2; s2++)
+            for (size_t k = 0; k < order[s2].size(); k++) CHECK(order[s2][k] == k);      // each handle delivers in submission order
     }
     std::puts("cpp tests ok");
     return 0;

@@ -3,9 +3,10 @@
 # objects of the normal build (ros_gpu_stereo_processor_amd/lib/obj).  usage: tools/ab_c4.sh <tag> [extra hipcc flags]
 set -e
 TAG=$1; shift
+TU=${C4_TU:-ra}   # translation unit to recompile: ra (R 2-4), rb (5-8), rc (9-11), rd (12-15)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OBJ=$ROOT/ros_gpu_stereo_processor_amd/lib/obj; OUT=$ROOT/tools/ab; mkdir -p $OUT
 hipcc -c --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-unused-function "$@" -I $ROOT/include -I $ROOT/ros_gpu_stereo_processor_amd/csrc \
-  $ROOT/ros_gpu_stereo_processor_amd/csrc/k_stereobm_c4_ra.hip -o $OUT/c4_$TAG.o
-hipcc -shared --offload-arch=gfx950 -o $OUT/lib_$TAG.so $OUT/c4_$TAG.o $(ls $OBJ/*.o | grep -v k_stereobm_c4_ra.o)
+  $ROOT/ros_gpu_stereo_processor_amd/csrc/k_stereobm_c4_$TU.hip -o $OUT/c4_$TAG.o
+hipcc -shared --offload-arch=gfx950 -o $OUT/lib_$TAG.so $OUT/c4_$TAG.o $(ls $OBJ/*.o | grep -v k_stereobm_c4_$TU.o)
 echo built $OUT/lib_$TAG.so
