@@ -274,6 +274,9 @@ typedef struct gip_streamer_config {
     int32_t depth;           /* ring slots = batches in flight (>= 2; 0 -> 3) */
     int32_t frames_per_batch;/* stereo pairs per compute launch (>= 1; 0 -> 1).  1 = lowest latency; larger batches fill the GPU
                               * (a single 1242x375 pair occupies a tenth of it) at the price of batch latency */
+    int32_t inputs_pinned;   /* 1: the raw images passed to gip_streamer_submit live in pinned (hipHostMalloc / hipHostRegister) memory with
+                              * tight rows and stay valid until their pair has been delivered: the H2D copy then reads them in place and the
+                              * submitting thread copies nothing */
 } gip_streamer_config;
 typedef struct gip_streamer_result {
     uint64_t seq;                 /* submission index of this pair (0, 1, ...) */

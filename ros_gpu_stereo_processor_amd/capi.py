@@ -87,7 +87,7 @@ class BatchDesc(C.Structure):
 
 class StreamerConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32), ("want_disparity16", C.c_int32),
-                ("depth", C.c_int32), ("frames_per_batch", C.c_int32)]
+                ("depth", C.c_int32), ("frames_per_batch", C.c_int32), ("inputs_pinned", C.c_int32)]
 
 
 class StreamerResult(C.Structure):

@@ -42,6 +42,7 @@ struct Slot {
     int count = 0;                              // pairs in this batch
     uint64_t first_seq = 0;
     std::vector<gip_header> headers;
+    std::vector<const void*> src[2];            // inputs_pinned: the caller's images of this batch
     Delivery delivery;
 };
 
@@ -102,7 +103,12 @@ int launch_slot(gip_streamer_s* s, Slot& sl)
     const size_t npx = s->npx;
     S_HIP(s, hipSetDevice(s->device));
     // copy-in
-    for (int e = 0; e < 2; e++) S_HIP(s, hipMemcpyAsync(sl.d_in[e], sl.h_in[e], s->in_bytes * B, hipMemcpyHostToDevice, s->s_in));
+    if (s->cfg.inputs_pinned) {
+        for (int e = 0; e < 2; e++)
+            for (int i = 0; i < B; i++) S_HIP(s, hipMemcpyAsync(sl.d_in[e] + s->in_bytes * i, sl.src[e][i], s->in_bytes, hipMemcpyHostToDevice, s->s_in));
+    } else {
+        for (int e = 0; e < 2; e++) S_HIP(s, hipMemcpyAsync(sl.d_in[e], sl.h_in[e], s->in_bytes * B, hipMemcpyHostToDevice, s->s_in));
+    }
     S_HIP(s, hipEventRecord(sl.ev_in, s->s_in));
     // compute: the whole chain on the batch
     S_HIP(s, hipStreamWaitEvent(s->s_comp, sl.ev_in, 0));
@@ -203,9 +209,11 @@ int gip_streamer_open(gip_handle h, const gip_streamer_config* cfg, gip_streamer
         sl.owner = s;
         sl.delivery.slot = &sl;
         sl.headers.resize(B);
+        sl.src[0].resize(B);
+        sl.src[1].resize(B);
         bool ok = true;
         for (int e = 0; e < 2; e++) {
-            ok = ok && hipHostMalloc((void**)&sl.h_in[e], s->in_bytes * B, hipHostMallocDefault) == hipSuccess;
+            if (!cfg->inputs_pinned) ok = ok && hipHostMalloc((void**)&sl.h_in[e], s->in_bytes * B, hipHostMallocDefault) == hipSuccess;
             ok = ok && hipMalloc((void**)&sl.d_in[e], s->in_bytes * B) == hipSuccess;
         }
         ok = ok && hipMalloc((void**)&sl.d_d16, s->npx * 2 * B) == hipSuccess;
@@ -236,7 +244,12 @@ int gip_streamer_submit(gip_streamer s, const void* left_raw, const void* right_
     }
     if (sl.count == 0) sl.first_seq = s->next_seq;
     const void* src[2] = {left_raw, right_raw};
+    if (s->cfg.inputs_pinned && step != row) return GIP_ERR_INVALID_ARG;   // in-place H2D needs tight rows
     for (int e = 0; e < 2; e++) {
+        if (s->cfg.inputs_pinned) {
+            sl.src[e][sl.count] = src[e];
+            continue;
+        }
         uint8_t* dst = sl.h_in[e] + s->in_bytes * sl.count;
         if (step == row) std::memcpy(dst, src[e], s->in_bytes);
         else

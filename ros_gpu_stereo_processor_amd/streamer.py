@@ -12,13 +12,14 @@ from .pipeline import ENCODINGS
 
 class Streamer:
     def __init__(self, proc, width, height, encoding="mono8", outputs=capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, want_disparity16=False, depth=3,
-                 frames_per_batch=1, on_result=None):
+                 frames_per_batch=1, on_result=None, inputs_pinned=False):
         """proc: a GpuStereoProcessor with model and parameters set.  on_result(seq, header, d16, f32, cloud): called per pair with
-        numpy COPIES (None for outputs not requested)."""
+        numpy COPIES (None for outputs not requested).  inputs_pinned: the arrays given to submit() are views of pinned memory (e.g.
+        torch.from_numpy(x).pin_memory().numpy()) that stay alive until delivered; they are then read in place by the H2D copy."""
         self._lib = capi.lib()
         self.proc = proc
         self.w, self.h = width, height
-        cfg = capi.StreamerConfig(width, height, ENCODINGS[encoding], outputs, 1 if want_disparity16 else 0, depth, frames_per_batch)
+        cfg = capi.StreamerConfig(width, height, ENCODINGS[encoding], outputs, 1 if want_disparity16 else 0, depth, frames_per_batch, 1 if inputs_pinned else 0)
         self._on_result = on_result
         self._errors = []
 

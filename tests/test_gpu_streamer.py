@@ -80,6 +80,18 @@ def test_streamer_counts_without_callback_and_rejects_bad_config(gpu):
     st.flush()
     assert st.delivered() == 9
     st.close()
+    # pinned inputs are read in place by the H2D copy (no staging memcpy): same results
+    import torch
+    pl, pr = torch.from_numpy(l).pin_memory(), torch.from_numpy(r).pin_memory()
+    got = []
+    ref = []
+    for pinned, sink, a, b in ((False, ref, l, r), (True, got, pl.numpy(), pr.numpy())):
+        st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY, depth=2, frames_per_batch=2, inputs_pinned=pinned, on_result=lambda seq, hdr, d16, f32, pc, sink=sink: sink.append(f32))
+        for _ in range(5):
+            st.submit(a, b)
+        st.flush()
+        st.close()
+    assert len(got) == 5 and all(np.array_equal(x, ref[0]) for x in got + ref)
     with pytest.raises(capi.GipError):
         Streamer(proc, w + 2, h, "mono8", capi.TOPIC_DISPARITY)      # size differs from the calibration
     with pytest.raises(capi.GipError):
