@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--rowsplit", action="store_true", help="BASELINE configs[4] mode: ONE frame per step cut into row tiles over the ranks (halo exchange + distributed "
                     "speckle over RCCL); use with --workload uhd4k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end streaming measurement (host memory in, host memory out)")
     args = ap.parse_args()
@@ -361,7 +362,7 @@ def main():
     pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True, fused_front_end=args.fused_front_end)
              for _ in range(max(1, args.depth))]
     streams = [torch.cuda.Stream(device=dev) for _ in pipes]
-    matcher_stream = torch.cuda.Stream(device=dev) if (len(pipes) > 1 and shared_matcher) else None
+    matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if (len(pipes) > 1 and shared_matcher) else None
     for p in pipes:
         p.install_maps(maps)
 

@@ -935,6 +935,7 @@ size_t gipk_stereobm_scratch_bytes(int w, int h, int batch, const gip_bm_params*
 int gipk_stereobm(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                   void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream)
 {
+    GIPK_ARGCHECK(left && right);   // (null inputs mean "planes already prefiltered" to the internal entry point only)
     return gip_stereobm_impl(left, right, pitch, w, h, p, disp, disp_pitch, scratch, scratch_bytes, batch, img_bstride, disp_bstride, stream, nullptr);
 }
 
