@@ -249,11 +249,19 @@ def rowsplit_main(args, wl):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # GIP_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with ONE GPU -- every rank uses device 0 and the collectives go
+    # over gloo (RCCL refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
+    rehearse = os.environ.get("GIP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lraw, rraw, calib0 = make_inputs(2, seed0=100, nseeds=2)       # the same two frames on every rank (the raw frame is resident everywhere)
     calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
     params = capi.BMParams(**bm_kwargs())
@@ -338,11 +346,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # GIP_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with ONE GPU -- every rank uses device 0 and the collectives go
+    # over gloo (RCCL refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
+    rehearse = os.environ.get("GIP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ros_gpu_stereo_processor_amd import dist as gdist
     B = args.batch

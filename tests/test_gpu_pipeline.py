@@ -295,17 +295,30 @@ def test_rowsplit_frame_single_rank_equals_pipeline(gpu, oracle):
     assert np.array_equal(nan_mask, exp == -16)
 
 
-@pytest.mark.gpu
-def test_nccl_broadcast_and_halo_exchange_two_devices(gpu):
-    """The two collectives of the multi-GPU modes over RCCL ("nccl" backend): the model broadcast of the frame-sharded mode and the
-    halo exchange + border all-gather of the row-tile split.  Needs two visible devices; the 1-GPU test box skips it."""
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs >= 2 GPUs (the driver's 8-GPU node runs the N > 1 bench)")
+def _run_selftest(nproc, port, rehearse):
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+    if rehearse:
+        env["GIP_BENCH_REHEARSE"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(root, "tools", "nccl_selftest.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "nccl selftest ok" in out.stdout
+    assert "selftest ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_multirank_paths_three_processes_one_gpu(gpu):
+    """The N > 1 code paths with REAL processes: model broadcast of the frame-sharded mode, and the row-tile split of one frame (halo
+    exchange by batched isend/irecv, distributed speckle with the HIP labeler, border all-gather) over three ranks -- all on device 0 with
+    gloo as the transport, because RCCL refuses two ranks on one device.  The stitched disparity must equal the single-GPU frame."""
+    _run_selftest(3, 29518, rehearse=True)
+
+
+@pytest.mark.gpu
+def test_nccl_broadcast_and_halo_exchange_two_devices(gpu):
+    """The same over RCCL ("nccl" backend).  Needs two visible devices; the 1-GPU test box skips it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's 8-GPU node runs the N > 1 bench)")
+    _run_selftest(2, 29517, rehearse=False)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Two (or more) ranks over RCCL: (1) dist.broadcast_model, every rank must end with rank 0's tables; (2) the row-tile split of one frame
+"""Two (or more) ranks over RCCL (or, with GIP_BENCH_REHEARSE=1, over gloo with every rank on device 0): (1) dist.broadcast_model, every rank must end with rank 0's tables; (2) the row-tile split of one frame
 (rowsplit.rowsplit_frame: halo exchange by batched isend/irecv, border all-gather for the speckle merge) must reproduce the single-GPU
 disparity.  Launched by tests/test_gpu_pipeline.py::test_nccl_broadcast_and_halo_exchange_two_devices through torch.distributed.run."""
 import os
@@ -16,9 +16,15 @@ from ros_gpu_stereo_processor_amd import dist as D  # noqa: E402
 
 def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    rehearse = os.environ.get("GIP_BENCH_REHEARSE") == "1"     # one-GPU box: every rank on device 0, collectives over gloo
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if rehearse:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     w, h, nd = 640, 240, 64
     calib0 = synth.scaled_calibration(w, h)
     calib, maps = D.broadcast_model(calib0 if rank == 0 else None, w, h, dev)
@@ -35,7 +41,7 @@ def main():
     assert torch.equal(d, full[y0:y1]), "row-tile result differs from the single-GPU frame on rank %d" % rank
     dist.barrier()
     if rank == 0:
-        print("nccl selftest ok: %d ranks, %dx%d" % (world, w, h))
+        print("%s selftest ok: %d ranks, %dx%d" % ("gloo-on-one-GPU" if rehearse else "nccl", world, w, h))
     dist.destroy_process_group()
 
 
