@@ -97,3 +97,37 @@ def test_streamer_counts_without_callback_and_rejects_bad_config(gpu):
     with pytest.raises(capi.GipError):
         Streamer(proc, w, h, "mono8", 0)                              # nothing to deliver
     proc.close()
+
+
+def test_streamed_bayer_colour_cloud_equals_process_pair(gpu):
+    """Bayer input: debayer to mono (both eyes) and to BGR (left, the cloud's colour) inside the streamed chain."""
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd import processor as P
+    from ros_gpu_stereo_processor_amd.streamer import Streamer
+    w, h, nd = 384, 128, 32
+    proc, calib = _processor(w, h, nd, 11)
+    enc = "bayer_grbg8"
+    frames = []
+    for i in range(5):
+        l, r = synth.raw_pair(w, h, nd, seed=400 + i, calib=calib)[:2]
+        frames.append((synth.bayer_mosaic(synth.colorize(l, 1), enc), synth.bayer_mosaic(synth.colorize(r, 2), enc)))
+    exp = []
+    for l, r in frames:
+        proc.processPair(l, r, enc, capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD)
+        f32 = proc.downloadMat(P.L_DISPARITY_32F)
+        sid = proc.enqueueSendPoints(P.L_POINTS2, P.L_RECT_COLOR)
+        proc.waitForAllStreams()
+        exp.append((f32.copy(), proc.pointCloudMessage(sid)["data"].copy()))
+        proc.cleanSenders()
+    got = {}
+    st = Streamer(proc, w, h, enc, capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, depth=3, frames_per_batch=2, on_result=lambda seq, hdr, d16, f32, pc: got.__setitem__(seq, (f32, pc)))
+    for l, r in frames:
+        st.submit(l, r)
+    st.flush()
+    st.close()
+    assert sorted(got) == list(range(5))
+    for i in range(5):
+        assert np.array_equal(got[i][0], exp[i][0]), i
+        assert np.array_equal(got[i][1].view(np.uint8), exp[i][1].view(np.uint8)), i
+    assert len(np.unique(exp[0][1][..., 16:19].reshape(-1, 3), axis=0)) > 50        # the cloud really carries colour
+    proc.close()
