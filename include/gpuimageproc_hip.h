@@ -257,6 +257,15 @@ int gip_set_params(gip_handle h, const gip_bm_params *p);
 int gip_process_pair(gip_handle h, const void *left_raw, const void *right_raw, int rows, int cols, size_t step, int type,
                      const char *encoding, uint32_t connected_topics);
 
+/* ================================================================== ROS1 wire format of the published messages
+ * Body of sensor_msgs/Image, stereo_msgs/DisparityImage, sensor_msgs/PointCloud2 exactly as roscpp serialises what the reference's
+ * senders publish (src/GpuSenderImage.cpp, src/GpuSenderDisparity.cpp, src/GpuSenderPc2.cpp): little-endian, fields in declaration
+ * order, uint32 length prefixes on strings and arrays.  Host-only, no device needed.  `out` may be NULL (size query).  Returns the
+ * number of bytes of the message; a NEGATIVE value -n means `cap` was too small for the n bytes needed; 0 = invalid message. */
+int64_t gip_ros1_serialize_image(const gip_image_msg *msg, uint8_t *out, size_t cap);
+int64_t gip_ros1_serialize_disparity(const gip_disparity_msg *msg, uint8_t *out, size_t cap);
+int64_t gip_ros1_serialize_pointcloud2(const gip_pointcloud2_msg *msg, uint8_t *out, size_t cap);
+
 /* ================================================================== streaming pipeline (gip_streamer_*)
  * The host link of the nodelet: the reference uploads both raws per frame (src/StereoProcessor.cpp:179-180), runs the chain,
  * hands every output to a stream host callback (src/GpuSenderIfc.cpp:13-26) and then BLOCKS on waitForAllStreams()

@@ -188,6 +188,9 @@ PROTOTYPES = {
     "gip_batch_run": (_i, [_vp, C.POINTER(BatchDesc), _vp]),
     "gip_batch_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gip_batch_timing_reset": (_i, [_vp]),
+    "gip_ros1_serialize_image": (C.c_int64, [C.POINTER(ImageMsg), _vp, _sz]),
+    "gip_ros1_serialize_disparity": (C.c_int64, [C.POINTER(DisparityMsg), _vp, _sz]),
+    "gip_ros1_serialize_pointcloud2": (C.c_int64, [C.POINTER(PointCloud2Msg), _vp, _sz]),
     "gip_streamer_open": (_i, [_vp, C.POINTER(StreamerConfig), STREAMER_CB, _vp, C.POINTER(_vp)]),
     "gip_streamer_submit": (_i, [_vp, _vp, _vp, _sz, C.POINTER(Header)]),
     "gip_streamer_flush": (_i, [_vp]),
