@@ -555,36 +555,37 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             }
         }
 
-        // uniqueness: groups whose minimum is <= the per-column threshold, summed over the quarters
-        u32 cnt[4] = {0, 0, 0, 0};
+        // uniqueness: groups whose minimum is <= the per-column threshold, summed over the quarters.  The four per-column counts (at most
+        // ndisp / 4 = 64 each) travel PACKED in one dword, one byte per column: two lane shuffles instead of eight -- as four separate
+        // values the compiler serialised them into eight dependent LDS round trips per row.
+        u32 cpk = 0;
         if (a.uniq > 0) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const u32 ms = best[q] >> 8;
                 const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
+                u32 c = 0;
 #pragma unroll
-                for (int g = 0; g < NGK; g++) cnt[q] += (gmin[q][g] <= thr) ? 1u : 0u;
-                if constexpr (!(C4_ABLATE & 8)) {
-                    cnt[q] += (u32)__shfl_xor((int)cnt[q], 16);
-                    cnt[q] += (u32)__shfl_xor((int)cnt[q], 32);
-                }
+                for (int g = 0; g < NGK; g++) c += (gmin[q][g] <= thr) ? 1u : 0u;
+                cpk |= c << (8 * q);
+            }
+            if constexpr (!(C4_ABLATE & 8)) {
+                cpk += (u32)__shfl_xor((int)cpk, 16);
+                cpk += (u32)__shfl_xor((int)cpk, 32);
             }
             if constexpr (NW > 1) {
-                if (sl == 0) *(uint4*)(xcnt + (wave * 16 + t) * 4) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+                if (sl == 0) xcnt[wave * 16 + t] = cpk;
                 wg_sync();                // a.uniq is uniform: every wave takes this branch
-                cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+                cpk = 0;
 #pragma unroll
-                for (int w2 = 0; w2 < NW; w2++) {
-                    const uint4 o = *(const uint4*)(xcnt + (w2 * 16 + t) * 4);
-                    cnt[0] += o.x; cnt[1] += o.y; cnt[2] += o.z; cnt[3] += o.w;
-                }
+                for (int w2 = 0; w2 < NW; w2++) cpk += xcnt[w2 * 16 + t];
             }
         }
         // ---- finalise pixel (column 4t+qf) in this lane
         if (!ROT || wave == ((y - ya) & (NW - 1))) {
         const u32 key = qf == 0 ? best[0] : qf == 1 ? best[1] : qf == 2 ? best[2] : best[3];
         const int tsum = (int)(qf == 0 ? tsum_q[0] : qf == 1 ? tsum_q[1] : qf == 2 ? tsum_q[2] : tsum_q[3]);
-        const int ngle = (int)(qf == 0 ? cnt[0] : qf == 1 ? cnt[1] : qf == 2 ? cnt[2] : cnt[3]);
+        const int ngle = (int)((cpk >> (8 * qf)) & 0xFFu);
         const int minsad = (int)(key >> 8), gstar = (int)(key & 0xFFu);
         int d_out = a.filtered;
         if constexpr (C4_ABLATE & 16) d_out = minsad + gstar + tsum + ngle;
