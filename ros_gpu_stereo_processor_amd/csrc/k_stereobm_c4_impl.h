@@ -101,6 +101,28 @@ struct P2 { u32 lo, hi; };
 __device__ __forceinline__ P2 operator+(P2 a, P2 b) { return {a.lo + b.lo, a.hi + b.hi}; }
 __device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi - b.hi}; }
 
+#ifndef C4_SWAPRED
+#define C4_SWAPRED 1    // 1: quarter merges by v_permlane16_swap / v_permlane32_swap (VALU only); 0: two ds_bpermute round trips
+#endif
+// Reduction of a value over the four lanes t, t+16, t+32, t+48 (the disparity quarters of one column group), result in all four, for a
+// commutative, associative op.  gfx950 has two VALU lane-swap instructions for exactly this (measured: tools/probe/permlane_swap_probe.hip):
+// v_permlane16_swap a, b exchanges the ODD 16-lane rows of a with the EVEN rows of b, v_permlane32_swap the upper half of a with the lower
+// half of b.  With a = b = x:  a' = {x.r0, x.r0, x.r2, x.r2}, b' = {x.r1, x.r1, x.r3, x.r3}, so op(a', b') is the xor-16 butterfly step in every
+// lane, and the same with halves for xor-32 -- no LDS round trip (ds_bpermute: the wave parks ~100+ cycles per dependent step).
+template <typename Op>
+__device__ __forceinline__ u32 quarters_reduce(u32 x, Op op)
+{
+#if C4_SWAPRED
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    x = op((u32)r[0], (u32)r[1]);
+    auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return op((u32)h[0], (u32)h[1]);
+#else
+    x = op(x, (u32)__shfl_xor((int)x, 16));
+    return op(x, (u32)__shfl_xor((int)x, 32));
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Column-wise window sum (border tiles): output column q of this lane from the in-lane prefix sums P[0..4] (P[0] = 0):
 //   window = columns [4t+q-R, 4t+q+R];  lane t+d covers columns 4(t+d)..4(t+d)+3  ->  sub-columns [lo,hi]
@@ -540,8 +562,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if constexpr (C4_ABLATE & 8) break;
-            best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 16));
-            best[q] = umin(best[q], (u32)__shfl_xor((int)best[q], 32));
+            best[q] = quarters_reduce(best[q], [](u32 x, u32 y) { return umin(x, y); });
         }
         if constexpr (NW > 1) {
             if (sl == 0) *(uint4*)(xbest + (wave * 16 + t) * 4) = make_uint4(best[0], best[1], best[2], best[3]);
@@ -570,8 +591,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 cpk |= c << (8 * q);
             }
             if constexpr (!(C4_ABLATE & 8)) {
-                cpk += (u32)__shfl_xor((int)cpk, 16);
-                cpk += (u32)__shfl_xor((int)cpk, 32);
+                cpk = quarters_reduce(cpk, [](u32 x, u32 y) { return x + y; });
             }
             if constexpr (NW > 1) {
                 if (sl == 0) xcnt[wave * 16 + t] = cpk;
