@@ -624,6 +624,8 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 uint4 A = *(const uint4*)(csrow_r + (has_m ? gstar - 1 : gstar) * 16);
                 const uint4 B = *(const uint4*)(csrow_r + gstar * 16);
                 uint4 Cn = *(const uint4*)(csrow_r + (has_p ? gstar + 1 : gstar) * 16);
+                // keep all three reads in ONE round trip: without this the compiler sinks the halves only the uniqueness test uses into its branch
+                asm volatile("" : "+v"(A.x), "+v"(A.y), "+v"(Cn.z), "+v"(Cn.w));
                 if (!has_m) A = make_uint4(~0u, ~0u, ~0u, ~0u);
                 if (!has_p) Cn = make_uint4(~0u, ~0u, ~0u, ~0u);
                 const u32 mlo = pk_min_u16(B.x, B.y);

@@ -68,6 +68,10 @@ KERNEL32(k_lshlrev, "v_lshlrev_b32 %0, 3, %0")
 KERNEL32(k_bfe, "v_bfe_u32 %0, %0, 8, 8")
 KERNEL32(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
 KERNEL32(k_add_dpp, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+KERNEL32(k_add_wshr, "v_add_u32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+KERNEL32(k_sub_wshl, "v_sub_u32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+KERNEL32(k_pl16swap, "v_permlane16_swap_b32 %0, %1")
+KERNEL32(k_pl32swap, "v_permlane32_swap_b32 %0, %1")
 KERNEL32(k_add3, "v_add3_u32 %0, %0, %1, %2")
 KERNEL32(k_cmp_addc, "v_cmp_le_u32 vcc, %1, %0\n v_addc_co_u32 %0, vcc, 0, %0, vcc")
 KERNEL32(k_min_sdwa, "v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1")
@@ -98,7 +102,7 @@ int main() {
                   {"v_add_u32", k_add_u32}, {"v_lshl_or_b32", k_lshl_or}, {"v_alignbyte_b32", k_alignbyte}, {"v_perm_b32", k_perm},
                   {"v_min_u16", k_min_u16}, {"v_min_u32_dpp", k_dpp_min}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_sub_u32_sdwa", k_sub_sdwa},
                   {"v_lshl_add_u64", k_lshl_add_u64}, {"v_sub_u32", k_sub_u32}, {"v_and_b32", k_and_b32}, {"v_or_b32", k_or_b32}, {"v_lshlrev_b32", k_lshlrev},
-                  {"v_bfe_u32", k_bfe}, {"v_mov_b32_dpp", k_mov_dpp}, {"v_add_u32_dpp", k_add_dpp}, {"v_add3_u32", k_add3},
+                  {"v_bfe_u32", k_bfe}, {"v_mov_b32_dpp", k_mov_dpp}, {"v_add_u32_dpp", k_add_dpp}, {"v_add_u32_dpp wave_shr:1", k_add_wshr}, {"v_sub_u32_dpp wave_shl:1", k_sub_wshl}, {"v_permlane16_swap", k_pl16swap}, {"v_permlane32_swap", k_pl32swap}, {"v_add3_u32", k_add3},
                   {"v_cmp_le+v_addc_co (2)", k_cmp_addc}, {"v_min_u32_sdwa", k_min_sdwa}, {"v_cndmask_b32", k_cndmask}, {"v_cndmask_b32_e64 sgpr", k_cndmask_s}, {"v_cmp_le+v_cndmask (2)", k_cmp_cnd}, {"v_cmp_le vcc", k_cmp_only},
                   {"v_cmp_le_e64 sgpr", k_cmp_s}, {"v_max_i16", k_max_i16}, {"v_med3_u32", k_med3}, {"v_mul_lo_u32", k_mul_lo},
                   {"v_mul_u32_u24", k_mul_u24}, {"v_max_u32", k_max_u32}, {"v_min_i32", k_min_i32}, {"v_xor_b32", k_xor}};
