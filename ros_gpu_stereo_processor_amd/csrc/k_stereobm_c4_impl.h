@@ -19,8 +19,8 @@
 //     i.e. for block 9:  H0 = A + P1(t+1),  H1 = A - P1(t-1) + P2(t+1),  H2 = A - P2(t-1) + P3(t+1),  H3 = A - P3(t-1) + T(t+1),
 //     A = T + T(t-1):  8 instructions per dword, every one a v_add_u32_dpp / v_sub_u32_dpp that fetches its neighbour-lane
 //     operand through the DPP row shift (hsum_pf below; the column-wise form took 21 per dword; a subtraction is written
-//     t = x(d) - acc; H = y(e) - t  because the DPP subtract always has the SHIFTED operand as minuend).  Outputs are valid for lanes
-//     t in [K, 15-K], K = ceil(r/4); tiles advance by 64-8K columns.
+//     t = x(d) - acc; H = y(e) - t  because the DPP subtract always has the SHIFTED operand as minuend).  Outputs are valid for
+//     the columns whose window lies inside the tile, 4t+q in [r, 63-r]; tiles advance by 64-2r columns.
 //   * BORDER tiles (the clamped-column rule of OpenCV applies somewhere in the tile) keep the four column sums V0..V3 themselves
 //     (one live reference byte per v_mqsad, byte position = clamped column) and form the window sums column-wise.
 //   * Winner-take-all: per 4-disparity group a packed min and one 32-bit key (cost << 8 | group); quarters are merged with
@@ -34,6 +34,7 @@
 #include "bm_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -286,7 +287,6 @@ __device__ __forceinline__ void hsum_pf(u32 T, u32 P1, u32 P2, u32 P3, u32& H0, 
 template <int NG, int R, int NW, bool PF>
 __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb, int img)
 {
-    constexpr int K = (R + 3) / 4;
     constexpr int NRING = 2 * R + 1;
     constexpr int NS = 4 * NW;                  // disparity slices
     constexpr int NT = 64 * NW;                 // threads
@@ -463,7 +463,9 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     const int qf = ROT ? sl : ((wave * QPW + sl) & 3);
     const int my_col = 4 * t + qf;
     const int c_out = c0 + my_col;
-    const bool writer = fin && (t >= K) && (t <= 15 - K) && (c_out >= a.cbeg) && (c_out < a.cend);
+    // a column is valid when its whole window lies inside the tile's 64 columns (column granularity, not lane granularity: for a radius that
+    // is not a multiple of 4 the outermost live lanes still produce 4 - R % 4 ... valid columns each)
+    const bool writer = fin && (my_col >= R) && (my_col <= 63 - R) && (c_out >= a.cbeg) && (c_out < a.cend);
     // cost slice rows ordered [q][t] (row = 16q + t): the stores of consecutive lanes are CSPB = 4 (mod 32) dwords apart
     // (bank-conflict free)
     constexpr int QSTRIDE = 16 * CSPB;
@@ -704,7 +706,6 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
 template <int NG, int R, int NW>
 __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 {
-    constexpr int K = (R + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so with the natural order
     // neighbouring tiles -- which share 2/3 of their right-image window and all of their rows -- would land on 8 different L2s.
@@ -725,7 +726,7 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 #else
     tile = blockIdx.x; chunk = blockIdx.y; img = blockIdx.z;
 #endif
-    const int c0 = a.cbeg - 4 * K + tile * (64 - 8 * K);   // relative column of lane t=0, q=0
+    const int c0 = a.cbeg - R + tile * (64 - 2 * R);   // relative column of lane t=0, q=0: tiles overlap by exactly 2R columns
     const int ya = a.row0 + chunk * a.rows_per_chunk;
     const int yb = min(ya + a.rows_per_chunk, a.row1);
     if (ya >= yb) return;
@@ -742,17 +743,18 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 template <int NG, int R, int NW>
 int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
-    constexpr int K = (R + 3) / 4;
     constexpr int NS = 4 * NW;
     constexpr int RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
     const size_t sh = (size_t)(2 * R + 1) * SLOTD * 4 + (size_t)64 * (2 * 4 * NG * NS + 16) + (size_t)2 * NW * 64 * 4;
     const int ncols = a.cend - a.cbeg;
-    const int ntiles = (ncols + (64 - 8 * K) - 1) / (64 - 8 * K);
+    const int ntiles = (ncols + (64 - 2 * R) - 1) / (64 - 2 * R);
     const int nrows = a.row1 - a.row0;
-    // Row chunks.  A CU holds min(32 / NW, floor(160 KiB / LDS per workgroup)) workgroups.  Pick the chunk count that
-    // minimises  rounds x (rows per chunk + warm-up cost): whole "rounds" of resident workgroups matter because a partially
-    // filled last round idles most of the chip, and every chunk re-reads 2R warm-up rows (each worth about 0.4 of a full row:
-    // SAD only, no winner-take-all).
+    // Row chunks.  A CU holds min(32 / NW, floor(160 KiB / LDS per workgroup), what the VGPRs allow) workgroups.  Pick the chunk count
+    // that minimises  (rounds + 0.5) x (rows per chunk + warm-up cost): whole "rounds" of resident workgroups matter because a partially
+    // filled last round idles most of the chip, every chunk re-reads 2R warm-up rows (each worth about 0.4 of a full row: SAD only,
+    // no winner-take-all), and the workgroups do not all take the same time (border tiles run the slower column form), which costs
+    // about half a workgroup's duration at the end whatever the fill.  The constants are fitted to forced-chunk sweeps of seven shapes
+    // (tools/chunk_sweep.sh, profiles/r02_chunk_sweep.txt): the pick is within 2 % of the best forced count on each.
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0, v = 0;
@@ -761,10 +763,23 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
     }
     int per_cu = (int)((160 * 1024) / (sh ? sh : 1));
     if (per_cu > 32 / NW) per_cu = 32 / NW;
+    // ... and no more waves per SIMD than the kernel's register count leaves room for (512 VGPRs per lane and SIMD, allocated in blocks of 8)
+    static int vgpr_waves = 0;      // one static per instantiation
+    if (vgpr_waves == 0) {
+        hipFuncAttributes fa;
+        vgpr_waves = 8;
+        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW>) == hipSuccess && fa.numRegs > 0) {
+            const int regs = (fa.numRegs + 7) & ~7;
+            vgpr_waves = 512 / regs < 1 ? 1 : (512 / regs > 8 ? 8 : 512 / regs);
+        }
+    }
+    if (per_cu > 4 * vgpr_waves / NW) per_cu = 4 * vgpr_waves / NW;
     if (per_cu < 1) per_cu = 1;
 #ifdef C4_FIXED_CHUNKS
     int nch = C4_FIXED_CHUNKS;
 #else
+    // measurement knob (tools/chunk_sweep.sh): GIP_C4_CHUNKS=n forces the chunk count; read once
+    static const int env_chunks = [] { const char* e = getenv("GIP_C4_CHUNKS"); return e ? atoi(e) : 0; }();
     const double capacity = (double)n_cu * per_cu;
     int nch = 1;
     double best_cost = 1e300;
@@ -774,9 +789,10 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
         const int real_c = (nrows + rpc - 1) / rpc;
         const double wgs = (double)ntiles * real_c * batch;
         const double rounds = wgs / capacity < 1.0 ? 1.0 : ceil(wgs / capacity - 1e-9);
-        const double cost = rounds * (rpc + 0.4 * 2 * R);
+        const double cost = (rounds + 0.5) * (rpc + 0.4 * 2 * R);
         if (cost < best_cost - 1e-9) { best_cost = cost; nch = real_c; }
     }
+    if (env_chunks > 0) nch = env_chunks < max_nch ? env_chunks : max_nch;
 #endif
     BmArgs b = a;
     b.rows_per_chunk = (nrows + nch - 1) / nch;
