@@ -313,7 +313,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="stereo pairs per step per GPU (default: 64 for kitti, 8 for hd1080, 1 for uhd4k)")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight per GPU (each on its own HIP stream with its own buffers): the pre/post "
                     "kernels of one batch run under the matcher of another.  Default per workload (kitti 3, others 2)")
-    ap.add_argument("--matcher-stream", choices=["auto", "shared", "own"], default="auto", help="shared: the matcher kernels of all batches in flight go to "
+    ap.add_argument("--matcher-stream", choices=["auto", "shared", "two", "own"], default="auto", help="shared: the matcher kernels of all batches in flight go to "
                     "ONE stream and run back to back (kitti, depth 3: 49.2k pairs/s against 43.2k with own streams); own: every batch keeps its "
                     "matcher on its own stream (better for the large-disparity workloads)")
     ap.add_argument("--fused-front-end", action="store_true", help="rectify + XSOBEL as ONE pass raw -> prefiltered plane (gipk_rectify_xsobel) instead of remap, then prefilter "
@@ -379,6 +379,11 @@ def main():
              for _ in range(max(1, args.depth))]
     streams = [torch.cuda.Stream(device=dev) for _ in pipes]
     matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if (len(pipes) > 1 and shared_matcher) else None
+    # "two": two matcher streams taken in turn, so that the ragged end of one matcher launch overlaps the start of the next
+    matcher_streams = [matcher_stream]
+    if args.matcher_stream == "two" and len(pipes) > 1:
+        matcher_stream = torch.cuda.Stream(device=dev)
+        matcher_streams = [matcher_stream, torch.cuda.Stream(device=dev)]
     for p in pipes:
         p.install_maps(maps)
 
@@ -398,7 +403,7 @@ def main():
         k = i % len(pipes)
         l, r = inputs[i % len(inputs)]
         with torch.cuda.stream(streams[k]):
-            pipes[k].run(l, r, matcher_stream)
+            pipes[k].run(l, r, matcher_streams[i % len(matcher_streams)])
     torch.cuda.synchronize()
 
     def barrier():
@@ -458,7 +463,7 @@ def main():
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * args.steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"], "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "matcher_stream": "shared" if matcher_stream is not None else "own",
+            "config": {"workload": wl["name"], "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
                        "parallelism": "frame-sharded x%d: frame g of a %d-frame bag -> rank g mod %d" % (world, BAG_FRAMES, world)},
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_ms": round(bm_ms, 4),
