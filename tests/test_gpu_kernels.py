@@ -399,3 +399,36 @@ def test_full_size_properties(gpu, oracle):
     twice = K.filter_speckles(once.clone(), -16, 800, 80)
     assert np.array_equal(_n(once), _n(twice))
     assert np.array_equal(_n(once)[1], oracle.filter_speckles(g[1], -16, 800, 80))
+
+
+def _fuzz_case(seed):
+    """seeded random matcher configuration: every (ndisp, block) the fast path instantiates, ragged widths around the tile stride 64 - 2r,
+    either sign of minDisparity, every combination of the optional tests"""
+    rng = np.random.default_rng(1000 + seed)
+    nd = 16 * int(rng.integers(1, 17))
+    block = 5 + 2 * int(rng.integers(0, 14))
+    r = block // 2
+    stride = 64 - 2 * r
+    # widths that put the last tile anywhere from one column to a full tile, sometimes a single tile
+    ntiles = int(rng.integers(1, 5))
+    width1 = max(1, (ntiles - 1) * stride + int(rng.integers(1, stride + 1)))
+    mind = int(rng.integers(-20, 11))
+    w = width1 + nd - 1 + abs(mind) if mind < 0 else width1 + nd - 1 + mind
+    w = max(w, block + 2)
+    h = block + 1 + int(rng.integers(1, 40))
+    tex = int(rng.choice([0, 5, 10]))
+    uniq = int(rng.choice([0, 10, 15, 25]))
+    d12 = int(rng.choice([-1, 0, 1, 2]))
+    return (w, h, nd, block, mind, tex, uniq, d12)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_bm_fuzz_bit_exact(gpu, oracle, seed):
+    from ros_gpu_stereo_processor_amd import kernels as K
+    case = _fuzz_case(seed)
+    w, h, nd, block, mind, tex, uniq, d12 = case
+    l, r, _ = synth.rectified_pair(w, h, min(nd, max(16, w // 3)), seed=5000 + seed)
+    kw = dict(block_size=block, num_disparities=nd, min_disparity=mind, texture_threshold=tex, uniqueness_ratio=uniq, disp12_max_diff=d12)
+    exp = oracle.stereobm(l, r, oracle.bm_params(**kw))
+    got = _n(K.stereobm(_t(l, gpu), _t(r, gpu), K.bm_params(**kw)))
+    assert np.array_equal(got, exp), case
