@@ -321,6 +321,7 @@ def main():
     ap.add_argument("--rowsplit", action="store_true", help="BASELINE configs[4] mode: ONE frame per step cut into row tiles over the ranks (halo exchange + distributed "
                     "speckle over RCCL); use with --workload uhd4k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain-priority", type=int, default=0, help="HIP stream priority of the per-batch streams that carry everything but the matcher (-1 = high)")
     ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end streaming measurement (host memory in, host memory out)")
@@ -377,7 +378,7 @@ def main():
     outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
     pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True, fused_front_end=args.fused_front_end)
              for _ in range(max(1, args.depth))]
-    streams = [torch.cuda.Stream(device=dev) for _ in pipes]
+    streams = [torch.cuda.Stream(device=dev, priority=args.chain_priority) for _ in pipes]
     matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if (len(pipes) > 1 and shared_matcher) else None
     # "two": two matcher streams taken in turn, so that the ragged end of one matcher launch overlaps the start of the next
     matcher_streams = [matcher_stream]
@@ -470,6 +471,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4),
                          # kernel_ms is the launch duration inside the timed region, where the kernels of the other batch in flight
                          # share the GPU; kernel_ms_alone is the same launch with nothing else running (three untimed steps)
+                         # (launched on the caller's own stream; for one-wave shapes with block >= 11 that is the matcher's refetch form,
+                         # inside the pipeline its ring form -- two stagings of the same kernel; identical at the metric's shape)
                          "kernel_ms_alone": round(bm_alone_ms, 4) if bm_alone_ms else None,
                          # the search is integer-VALU / latency bound, not HBM bound: (pixel, disparity) pairs per
                          # second times a FIXED algorithmic floor of issue slots per pair, against the measured VALU issue rate

@@ -277,6 +277,36 @@ __device__ __forceinline__ void hsum_pf(u32 T, u32 P1, u32 P2, u32 P3, u32& H0, 
     }
 }
 
+// LDS budget of one workgroup and the resulting workgroups per CU (by LDS and wave slots only; registers are looked at at launch).
+constexpr size_t c4_lds_bytes(int NG, int R, int NW, int nring)
+{
+    const int NS = 4 * NW, RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
+    return (size_t)nring * SLOTD * 4 + (size_t)64 * (2 * 4 * NG * NS + 16) + (size_t)2 * NW * 64 * 4;
+}
+constexpr int c4_per_cu(size_t lds, int NW)
+{
+    const size_t granule = 1280;          // LDS is handed out in 1/128ths of the 160 KiB
+    const int p = (int)((160 * 1024) / ((lds + granule - 1) / granule * granule));
+    return p > 32 / NW ? 32 / NW : p;
+}
+// REFETCH: the row ring (2r+1 rows, there so that the row LEAVING the window can be recomputed without touching memory again) grows
+// with the block size and, at large blocks, costs a whole workgroup per CU.  When it does, the kernel keeps only two staging slots
+// and fetches the leaving row a second time through L2 (the same workgroup loaded it 2r+1 iterations earlier, its neighbours too):
+// one more dword load per thread and row buys up to a third more resident waves (nd 128 / block 21: 6 -> 8 workgroups per CU, -13.5 %;
+// nd 64 / block 15: -12 %).  One-wave workgroups only: with several waves the extra staging needs two barriers per warm-up row and the
+// measured result is a loss (nd 256 / block 21, 3 -> 4 workgroups per CU: +5 %; nd 192 / block 15: +3 %).
+// C4_REFETCH: 0 never, 1 when it raises the workgroups per CU of a one-wave shape, 2 always.
+#ifndef C4_REFETCH
+#define C4_REFETCH 1
+#endif
+constexpr bool c4_refetch(int NG, int R, int NW)
+{
+    // (more than 16 one-wave workgroups per CU are not resident anyway: these shapes use 100+ VGPRs, i.e. at most 4 waves per SIMD)
+    const int with = c4_per_cu(c4_lds_bytes(NG, R, NW, 2), NW), without = c4_per_cu(c4_lds_bytes(NG, R, NW, 2 * R + 1), NW);
+    // NG > 12 (nd 208 / 240) holds all 256 VGPRs: register-bound whatever the LDS says (measured: +6 % with the refetch)
+    return C4_REFETCH == 2 || (C4_REFETCH == 1 && NW == 1 && NG <= 12 && (with < 16 ? with : 16) > (without < 16 ? without : 16));
+}
+
 // NW = wavefronts per workgroup.  NW = 1 is the layout described above.  With NW > 1 the waves of a workgroup work on the SAME
 // 64 columns and split the disparity range further (slice s = 4 * wave + lane / 16 of NS = 4 * NW slices): they share the row
 // ring and the cost slice, so the LDS per wave -- what limits the number of resident waves -- drops by NW, and so do the
@@ -284,10 +314,11 @@ __device__ __forceinline__ void hsum_pf(u32 T, u32 P1, u32 P2, u32 P3, u32& H0, 
 // through LDS, the texture sums are computed by every wave, and a wave finalises only 64 / NW pixels per row.
 //
 // PF: prefix form (interior tile) or column form (border tile); uniform per workgroup.
-template <int NG, int R, int NW, bool PF>
+template <int NG, int R, int NW, bool PF, bool RF>
 __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb, int img)
 {
-    constexpr int NRING = 2 * R + 1;
+    constexpr int NRING = RF ? 2 : 2 * R + 1;   // RF: slot 0 = the entering row, slot 1 = the leaving row
+    static_assert(!(RF && C4_PIPE), "the early-subtract variant reads the ring");
     constexpr int NS = 4 * NW;                  // disparity slices
     constexpr int NT = 64 * NW;                 // threads
     constexpr int NDISP = 4 * NG * NS;
@@ -353,20 +384,23 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
 #pragma unroll
         for (int q = 0; q < 4; q++) psh[q] = 8u * (u32)((clampi(c0 + 4 * t + q, rlo, rhi) - c0) & 3);
     }
-    u32 pf_l = 0, pf_r[NLD];
-    auto prefetch = [&](int yy) {
-        if (tid < 16) pf_l = fetch_l(yy);
+    struct PfRegs { u32 l; u32 r[NLD]; };
+    PfRegs pfE = {}, pfS = {};        // the row entering the window next; (RF) the row leaving it next
+    auto prefetch_to = [&](PfRegs& pf, int yy) {
+        if (tid < 16) pf.l = fetch_l(yy);
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (tid + NT * i < RWD) pf_r[i] = fetch(Rb, yy, rdw + NT * i, rsh);
+            if (tid + NT * i < RWD) pf.r[i] = fetch(Rb, yy, rdw + NT * i, rsh);
     };
-    auto commit = [&](int yy) {
-        u32* slot = ring + (yy % NRING) * SLOTD;
-        if (tid < 16) slot[tid] = pf_l;
+    auto commit_to = [&](const PfRegs& pf, int sidx) {
+        u32* slot = ring + sidx * SLOTD;
+        if (tid < 16) slot[tid] = pf.l;
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (tid + NT * i < RWD) slot[16 + tid + NT * i] = pf_r[i];
+            if (tid + NT * i < RWD) slot[16 + tid + NT * i] = pf.r[i];
     };
+    auto prefetch = [&](int yy) { prefetch_to(pfE, yy); };
+    auto commit = [&](int yy) { commit_to(pfE, RF ? 0 : yy % NRING); };
 
     // ---- state
     // PF:  V[j][g] = prefix sum over columns 0..j of the vertical column sums (V[3] = T), TV[j] likewise for |L - ftzero|
@@ -388,8 +422,8 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     // LDS ring and using it are separate steps so that the reads can be issued well ahead of the v_mqsad that consume them: with
     // two waves per SIMD an exposed LDS round trip is idle VALU time (SQ_WAIT_ANY, profiles/).
     struct RowRegs { u32 lw; u32 rd[NG + 1]; };
-    auto read_row = [&](int yy) -> RowRegs {
-        const u32* slot = ring + (yy % NRING) * SLOTD;
+    auto read_slot = [&](int sidx) -> RowRegs {
+        const u32* slot = ring + sidx * SLOTD;
         RowRegs r;
         r.lw = slot[t];
         const u32* rw = slot + 16 + tw + NG * s;
@@ -397,6 +431,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         for (int i = 0; i <= NG; i++) r.rd[i] = rw[i];
         return r;
     };
+    auto read_row = [&](int yy) -> RowRegs { return read_slot(yy % NRING); };   // (!RF)
     auto add_regs = [&](const RowRegs& r) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -445,13 +480,26 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     };
 
     // ---- warm-up: rows ya-R .. ya+R-1 enter the window
-    for (int yy = ya - R; yy < ya + R; yy++) {
-        prefetch(yy);
-        commit(yy);
+    if constexpr (RF) {
+        prefetch(ya - R);
+        for (int yy = ya - R; yy < ya + R; yy++) {
+            wg_sync();            // the previous row's reads of slot 0 are done
+            commit(yy);
+            wg_sync();
+            const RowRegs W = read_slot(0);
+            prefetch(yy + 1);     // (yy + 1 <= ya + R < h)
+            add_regs(W);
+        }
+        prefetch_to(pfS, ya - R);
+    } else {
+        for (int yy = ya - R; yy < ya + R; yy++) {
+            prefetch(yy);
+            commit(yy);
+        }
+        wg_sync();
+        for (int yy = ya - R; yy < ya + R; yy++) add_regs(read_row(yy));
+        prefetch(ya + R);
     }
-    wg_sync();
-    for (int yy = ya - R; yy < ya + R; yy++) add_regs(read_row(yy));
-    prefetch(ya + R);
 
     // the pixel this lane finalises: column 4t + qf.  One wave: qf = lane / 16.  NW waves: every wave ends up with the merged keys,
     // counts and texture sums of all four columns of its lanes, so ONE wave can finalise the whole row (qf = lane / 16, every lane
@@ -480,9 +528,11 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     for (int y = ya; y < yb; y++) {
         wg_sync();                // every wave is done with the slot row y+R replaces (its reads are in S)
         commit(y + R);
+        if constexpr (RF) commit_to(pfS, 1);        // row y-R
         wg_sync();
-        const RowRegs A = read_row(y + R);
+        const RowRegs A = RF ? read_slot(0) : read_row(y + R);
         if (y + R + 1 < a.h) prefetch(y + R + 1);
+        if constexpr (RF) prefetch_to(pfS, y - R + 1);
         if (C4_PIPE && y > ya && !(C4_ABLATE & 1)) sub_regs(S);
         add_regs(A);
 
@@ -559,7 +609,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             static_for<0, 4>([&](auto qv) { constexpr int q = decltype(qv)::value; tsum_q[q] = hsum<R, q>(P, shift); });
         }
         // the row that leaves the window next: issue its LDS reads now, they are consumed at the top of the next iteration
-        if (C4_PIPE && y + 1 < yb) S = read_row(y - R);
+        if constexpr (C4_PIPE != 0) { if (y + 1 < yb) S = read_row(y - R); }
         // merge the four disparity quarters (lanes t, t+16, t+32, t+48)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -699,11 +749,11 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             }
         }
         }   // finalising wave
-        if (!C4_PIPE && !(C4_ABLATE & 1)) sub_regs(read_row(y - R));
+        if (!C4_PIPE && !(C4_ABLATE & 1)) sub_regs(RF ? read_slot(1) : read_row(y - R));
     }
 }
 
-template <int NG, int R, int NW>
+template <int NG, int R, int NW, bool RF>
 __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -733,19 +783,17 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
     // interior tile: no column of the tile is touched by the right-image clamp (rofs + clamp(cc, -rofs, w - ndisp - rofs) + d)
     const bool interior = c0 >= -a.rofs && c0 + 63 <= a.w - a.ndisp - a.rofs;
 #ifdef C4_NO_PF
-    bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb, img);
+    bm_c4_tile<NG, R, NW, false, RF>(a, smem_raw, c0, ya, yb, img);
 #else
-    if (interior) bm_c4_tile<NG, R, NW, true>(a, smem_raw, c0, ya, yb, img);
-    else bm_c4_tile<NG, R, NW, false>(a, smem_raw, c0, ya, yb, img);
+    if (interior) bm_c4_tile<NG, R, NW, true, RF>(a, smem_raw, c0, ya, yb, img);
+    else bm_c4_tile<NG, R, NW, false, RF>(a, smem_raw, c0, ya, yb, img);
 #endif
 }
 
-template <int NG, int R, int NW>
-int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
+template <int NG, int R, int NW, bool RF>
+int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
-    constexpr int NS = 4 * NW;
-    constexpr int RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
-    const size_t sh = (size_t)(2 * R + 1) * SLOTD * 4 + (size_t)64 * (2 * 4 * NG * NS + 16) + (size_t)2 * NW * 64 * 4;
+    const size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1);
     const int ncols = a.cend - a.cbeg;
     const int ntiles = (ncols + (64 - 2 * R) - 1) / (64 - 2 * R);
     const int nrows = a.row1 - a.row0;
@@ -761,14 +809,13 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
         else n_cu = 256;
     }
-    int per_cu = (int)((160 * 1024) / (sh ? sh : 1));
-    if (per_cu > 32 / NW) per_cu = 32 / NW;
+    int per_cu = c4_per_cu(sh, NW);
     // ... and no more waves per SIMD than the kernel's register count leaves room for (512 VGPRs per lane and SIMD, allocated in blocks of 8)
     static int vgpr_waves = 0;      // one static per instantiation
     if (vgpr_waves == 0) {
         hipFuncAttributes fa;
         vgpr_waves = 8;
-        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW>) == hipSuccess && fa.numRegs > 0) {
+        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW, RF>) == hipSuccess && fa.numRegs > 0) {
             const int regs = (fa.numRegs + 7) & ~7;
             vgpr_waves = 512 / regs < 1 ? 1 : (512 / regs > 8 ? 8 : 512 / regs);
         }
@@ -803,7 +850,7 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
 #else
     const dim3 grid(ntiles, nch, batch);
 #endif
-    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW, RF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     // the matcher may run on a stream of its own (BmLaunchCtx::matcher_stream), fenced by events on both sides
     hipStream_t ks = st;
     const bool forked = ctx && ctx->matcher_stream && ctx->matcher_stream != st;
@@ -813,7 +860,7 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
         GIP_HIP_CHECK(hipStreamWaitEvent(ks, ctx->fork, 0));
     }
     if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, ks));
-    hipLaunchKernelGGL((k_bm_c4<NG, R, NW>), grid, dim3(64 * NW), sh, ks, b);
+    hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, b);
     GIP_LAUNCH_CHECK();
     if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, ks));
     if (forked) {
@@ -821,6 +868,21 @@ int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx
         GIP_HIP_CHECK(hipStreamWaitEvent(st, ctx->join, 0));
     }
     return GIP_OK;
+}
+
+// The refetch form is the faster kernel on its own (profiles/r02_matcher_refetch.txt) but the slower one inside the throughput pipeline,
+// where the matcher of one batch runs next to the small latency-bound kernels of two others: the extra matcher workgroups per CU crowd
+// those out and the STEP gets 1.5-3 % longer although the matcher gets 2-11 % shorter (same-box A/B, tools/bench_ab.sh).  So: refetch
+// when the matcher is launched on the caller's own stream (single calls, gip_process_pair, one batch in flight), the ring form when the
+// caller hands over a separate matcher stream (BmLaunchCtx::matcher_stream -- the batch pipeline with several batches in flight).
+template <int NG, int R, int NW>
+int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
+{
+    if constexpr (c4_refetch(NG, R, NW)) {
+        const bool pipelined = ctx && ctx->matcher_stream && ctx->matcher_stream != st;
+        if (!pipelined) return launch_c4_rf<NG, R, NW, true>(a, batch, st, ctx);
+    }
+    return launch_c4_rf<NG, R, NW, false>(a, batch, st, ctx);
 }
 
 // (groups per slice, waves) for a disparity count: ndisp = 16 * NG * NW.  The wave counts are measured choices (tools/bm_ab.py,
