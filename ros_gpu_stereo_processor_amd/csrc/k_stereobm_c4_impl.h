@@ -60,6 +60,9 @@
 #ifndef C4_XCD_MAP  /* 1: contiguous ranges of tiles per XCD (L2 locality) instead of the natural blockIdx order */
 #define C4_XCD_MAP 1
 #endif
+#ifndef C4_MINW     /* second argument of __launch_bounds__: waves per SIMD the register allocator must leave room for */
+#define C4_MINW 1
+#endif
 #ifndef C4_NOSYNC   /* 1: one-wave workgroups order their LDS traffic by program order only (no s_waitcnt drain) */
 #define C4_NOSYNC 1
 #endif
@@ -754,7 +757,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
 }
 
 template <int NG, int R, int NW, bool RF>
-__global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
+__global__ void __launch_bounds__(64 * NW, C4_MINW) k_bm_c4(BmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so with the natural order
@@ -793,7 +796,9 @@ __global__ void __launch_bounds__(64 * NW) k_bm_c4(BmArgs a)
 template <int NG, int R, int NW, bool RF>
 int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
-    const size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1);
+    // measurement knob: GIP_C4_LDS_PAD=n allocates n more bytes of LDS per workgroup (fewer matcher workgroups per CU; read once)
+    static const int env_pad = [] { const char* e = getenv("GIP_C4_LDS_PAD"); return e ? atoi(e) : 0; }();
+    const size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1) + (size_t)(env_pad > 0 ? env_pad : 0);
     const int ncols = a.cend - a.cbeg;
     const int ntiles = (ncols + (64 - 2 * R) - 1) / (64 - 2 * R);
     const int nrows = a.row1 - a.row0;
