@@ -364,13 +364,13 @@ int gip_create(int device, gip_handle* out)
 int gip_destroy(gip_handle h)
 {
     if (!h) return GIP_ERR_INVALID_ARG;
-    hipSetDevice(h->device);
-    if (h->l_strm) hipStreamSynchronize(h->l_strm);
-    if (h->r_strm) hipStreamSynchronize(h->r_strm);
-    gip_clean_senders(h);
+    (void)hipSetDevice(h->device);        // teardown: errors have nowhere to go, every resource is released regardless
+    if (h->l_strm) (void)hipStreamSynchronize(h->l_strm);
+    if (h->r_strm) (void)hipStreamSynchronize(h->r_strm);
+    (void)gip_clean_senders(h);
     for (auto& kv : h->slots) {
         Slot& s = kv.second;
-        if (s.d) hipFree(s.d);
+        if (s.d) (void)hipFree(s.d);
         for (int k = 0; k < 2; k++) {
             if (s.stage[k]) (void)hipHostFree(s.stage[k]);
             if (s.stage_done[k]) (void)hipEventDestroy(s.stage_done[k]);
@@ -381,18 +381,18 @@ int gip_destroy(gip_handle h)
     for (auto& pp : h->pinned_pool) (void)hipHostFree(pp.first);
     if (h->maps_owned)
         for (int i = 0; i < 2; i++) {
-            if (h->d_map1[i]) hipFree(h->d_map1[i]);
-            if (h->d_map2[i]) hipFree(h->d_map2[i]);
+            if (h->d_map1[i]) (void)hipFree(h->d_map1[i]);
+            if (h->d_map2[i]) (void)hipFree(h->d_map2[i]);
         }
     DevBuf* bufs[] = {&h->bm_scratch, &h->spk_scratch, &h->pc_dev, &h->b_mono[0], &h->b_mono[1], &h->b_color, &h->b_rect[0], &h->b_rect[1], &h->b_rect_color, &h->b_f32};
     for (DevBuf* b : bufs)
-        if (b->p) hipFree(b->p);
+        if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->tev)
         if (e) (void)hipEventDestroy(e);
     if (h->match_fork) (void)hipEventDestroy(h->match_fork);
     if (h->match_join) (void)hipEventDestroy(h->match_join);
-    if (h->l_strm) hipStreamDestroy(h->l_strm);
-    if (h->r_strm) hipStreamDestroy(h->r_strm);
+    if (h->l_strm) (void)hipStreamDestroy(h->l_strm);
+    if (h->r_strm) (void)hipStreamDestroy(h->r_strm);
     delete h;
     return GIP_OK;
 }
@@ -979,9 +979,9 @@ int gip_clean_senders(gip_handle h)
     if (h->senders.empty()) return GIP_OK;
     // a sender's payload may still be the target of an in-flight copy: drain first (the reference relies on
     // waitForAllStreams() before cleanSenders(), StereoProcessor.cpp:284-285)
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->l_strm);
-    hipStreamSynchronize(h->r_strm);
+    H_HIP(h, hipSetDevice(h->device));
+    H_HIP(h, hipStreamSynchronize(h->l_strm));
+    H_HIP(h, hipStreamSynchronize(h->r_strm));
     for (auto& s : h->senders)
         if (s->host) h->pinned_pool.emplace_back(s->host, s->host_bytes);
     h->senders.clear();
@@ -1100,7 +1100,7 @@ int gip_process_pair(gip_handle h, const void* left_raw, const void* right_raw, 
     if (!encoding || !encoding[0]) return fail(h, GIP_ERR_INVALID_ARG, "process_pair: empty encoding");
     int rc;
 #define STEP(expr) do { rc = (expr); if (rc != GIP_OK) return rc; } while (0)
-    gip_clean_senders(h);                                                                  // StereoProcessor.cpp:166
+    STEP(gip_clean_senders(h));                                                                // StereoProcessor.cpp:166
     STEP(gip_upload_mat(h, GIP_SIDE_L | GIP_SRC_RAW, left_raw, rows, cols, step, type, encoding));    // :179
     STEP(gip_upload_mat(h, GIP_SIDE_R | GIP_SRC_RAW, right_raw, rows, cols, step, type, encoding));   // :180
     const bool disp_any = c & (GIP_TOPIC_DISPARITY | GIP_TOPIC_DISPARITY_VIS | GIP_TOPIC_POINTCLOUD);
@@ -1129,8 +1129,8 @@ int gip_batch_set_maps_device(gip_handle h, int width, int height, const int16_t
     if (!map1_l || !map2_l || !map1_r || !map2_r || width <= 0 || height <= 0) return fail(h, GIP_ERR_INVALID_ARG, "batch_set_maps_device: bad arguments");
     if (h->maps_owned)
         for (int i = 0; i < 2; i++) {
-            if (h->d_map1[i]) hipFree(h->d_map1[i]);
-            if (h->d_map2[i]) hipFree(h->d_map2[i]);
+            if (h->d_map1[i]) (void)hipFree(h->d_map1[i]);
+            if (h->d_map2[i]) (void)hipFree(h->d_map2[i]);
         }
     h->maps_owned = false;
     h->d_map1[0] = (int16_t*)map1_l; h->d_map2[0] = (uint16_t*)map2_l;
