@@ -97,15 +97,17 @@ def test_batch_pipeline_odd_size_batch_of_four(gpu, oracle):
     pipe.close()
 
 
-def test_pipelines_in_flight_with_shared_matcher_stream(gpu):
+@pytest.mark.parametrize("block", [9, 15, 21])
+def test_pipelines_in_flight_with_shared_matcher_stream(gpu, block):
     """bench.py keeps three pipelines in flight (own streams, own buffers) whose matcher kernels go to ONE shared stream
-    (gip_batch_desc::matcher_stream).  Every pipeline must still produce exactly what it produces alone."""
+    (gip_batch_desc::matcher_stream).  Every pipeline must still produce exactly what it produces alone.  At block 15 / 21 the two runs
+    also use the two forms of the matcher's row staging (alone: refetch, with a matcher stream: ring; k_stereobm_c4_impl.h launch_c4)."""
     import torch
     from ros_gpu_stereo_processor_amd import capi
     from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
     w, h, nd, B = 480, 160, 64, 3
     calib = synth.scaled_calibration(w, h)
-    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=9, min_disparity=0, num_disparities=nd, texture_threshold=10,
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=block, min_disparity=0, num_disparities=nd, texture_threshold=10,
               uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
     pipes = [BatchPipeline(w, h, calib, capi.BMParams(**kw), B, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 0, 200, 4.0) for _ in range(3)]
     ins = []
