@@ -33,6 +33,7 @@
 #include "gip_internal.h"
 #include "bm_common.h"
 
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -864,10 +865,17 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
         GIP_HIP_CHECK(hipEventRecord(ctx->fork, st));
         GIP_HIP_CHECK(hipStreamWaitEvent(ks, ctx->fork, 0));
     }
-    if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, ks));
-    hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, b);
-    GIP_LAUNCH_CHECK();
-    if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, ks));
+    if (ctx && ctx->ev0 && ctx->ev1) {
+        // timing events attached to the dispatch itself: the pair brackets the kernel's own start and end timestamps (what rocprofv3 reports),
+        // not the command processor's walk from one event packet to the next (+25-30 us per launch when recorded around it)
+        hipExtLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, ctx->ev0, ctx->ev1, 0, b);
+        GIP_LAUNCH_CHECK();
+    } else {
+        if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, ks));
+        hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, b);
+        GIP_LAUNCH_CHECK();
+        if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, ks));
+    }
     if (forked) {
         GIP_HIP_CHECK(hipEventRecord(ctx->join, ks));
         GIP_HIP_CHECK(hipStreamWaitEvent(st, ctx->join, 0));
