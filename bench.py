@@ -307,8 +307,10 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 200 steps (a quarter of a second of GPU time at the default workload): the timed region necessarily contains one pipeline fill and one
+    # drain (about 1 ms with three batches in flight), which at 20 steps was 4 % of it
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti", help="kitti = BASELINE configs[1] (the metric's config); hd1080 = configs[2]; uhd4k = the frame of configs[4] on one GPU")
     ap.add_argument("--batch", type=int, default=0, help="stereo pairs per step per GPU (default: 64 for kitti, 8 for hd1080, 1 for uhd4k)")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight per GPU (each on its own HIP stream with its own buffers): the pre/post "
