@@ -865,21 +865,16 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
         GIP_HIP_CHECK(hipEventRecord(ctx->fork, st));
         GIP_HIP_CHECK(hipStreamWaitEvent(ks, ctx->fork, 0));
     }
-    if (ctx && ctx->ev0 && ctx->ev1) {
-        // timing events attached to the dispatch itself: the pair brackets the kernel's own start and end timestamps (what rocprofv3 reports),
-        // not the command processor's walk from one event packet to the next (+25-30 us per launch when recorded around it)
-        hipExtLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, ctx->ev0, ctx->ev1, 0, b);
-        GIP_LAUNCH_CHECK();
-    } else {
-        if (ctx && ctx->ev0) GIP_HIP_CHECK(hipEventRecord(ctx->ev0, ks));
-        hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, b);
-        GIP_LAUNCH_CHECK();
-        if (ctx && ctx->ev1) GIP_HIP_CHECK(hipEventRecord(ctx->ev1, ks));
-    }
-    if (forked) {
-        GIP_HIP_CHECK(hipEventRecord(ctx->join, ks));
-        GIP_HIP_CHECK(hipStreamWaitEvent(st, ctx->join, 0));
-    }
+    // Events attached to the dispatch itself (hipExtLaunchKernelGGL): the timing pair brackets the kernel's own start and end timestamps (what
+    // rocprofv3 reports; recorded around the launch they include 25-30 us of the command processor walking from packet to packet), and the stop
+    // event doubles as the join event of a forked launch -- one packet less on the matcher stream between two matcher launches.
+    hipEvent_t ev_start = ctx ? ctx->ev0 : nullptr;
+    hipEvent_t ev_stop = ctx ? ctx->ev1 : nullptr;
+    if (forked && !ev_stop) ev_stop = ctx->join;
+    if (ev_start || ev_stop) hipExtLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, ev_start, ev_stop, 0, b);
+    else hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, b);
+    GIP_LAUNCH_CHECK();
+    if (forked) GIP_HIP_CHECK(hipStreamWaitEvent(st, ev_stop, 0));
     return GIP_OK;
 }
 
