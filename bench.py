@@ -327,9 +327,16 @@ def main():
     ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end streaming measurement (host memory in, host memory out)")
+    ap.add_argument("--ndisp", type=int, default=0, help="experiment: override the workload's numDisparities (the metric's configuration is the default)")
+    ap.add_argument("--block", type=int, default=0, help="experiment: override the workload's block size")
     args = ap.parse_args()
     global W, H, NDISP, BLOCK, ENCODING
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.ndisp > 0 or args.block > 0:
+        wl["NDISP"] = args.ndisp if args.ndisp > 0 else wl["NDISP"]
+        wl["BLOCK"] = args.block if args.block > 0 else wl["BLOCK"]
+        wl["name"] = wl["name"] + " [EXPERIMENT: ndisp=%d block=%d]" % (wl["NDISP"], wl["BLOCK"])
+        wl["kernel"] = "k_bm_c4"
     W, H, NDISP, BLOCK, ENCODING = wl["W"], wl["H"], wl["NDISP"], wl["BLOCK"], wl["ENCODING"]
     if args.rowsplit:
         return rowsplit_main(args, wl)

@@ -186,9 +186,10 @@ __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, f
 #define SPK_STRIP_N 8
 #endif
 #ifndef SPK_CAP_N
-#define SPK_CAP_N 1280
+#define SPK_CAP_N 1264
 #endif
-// Strip height / LDS capacity are sized so that a strip workgroup needs 10 KB of LDS.  With 32-row strips (57 KB) the kernel took 642 us
+// Strip height / LDS capacity are sized so that a strip workgroup needs just under 10 KB of LDS (2 x 1264 x 4 + 72 = 10 184 <= 10 240, the room eight
+// matcher workgroups of the metric's shape leave on a CU).  With 32-row strips (57 KB) the kernel took 642 us
 // next to the matcher of another batch against 29 us alone: the matcher keeps every CU's 160 KB full with 20 KB workgroups that are
 // replaced one at a time, so a 57 KB request starves.  At 10 KB it takes 99 us co-scheduled (the ~3x every small kernel stretches by);
 // the global merge of the strip seams (k_spk_cross) grows from 17 to 31 us, throughput is unchanged (profiles/r02_stretch.txt).

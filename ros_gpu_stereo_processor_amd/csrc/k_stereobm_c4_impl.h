@@ -282,10 +282,34 @@ __device__ __forceinline__ void hsum_pf(u32 T, u32 P1, u32 P2, u32 P3, u32& H0, 
 }
 
 // LDS budget of one workgroup and the resulting workgroups per CU (by LDS and wave slots only; registers are looked at at launch).
+// Rows of the cost slice: one per (column q, live lane t).  The R / 4 lanes at either end of the 16-lane row hold no output column (their
+// columns' windows leave the tile); they still execute the parks, so each gets ONE dump row for all four of its columns.
+constexpr int c4_slice_rows(int R) { return 4 * (16 - 2 * (R / 4)); }
+// ... and the dump area of the halo lanes: one row's length plus room to shift each halo lane's stores onto the LDS banks its eight-lane store
+// group leaves free (a 16-byte store is issued eight lanes at a time over 32 banks; the seven or fewer live lanes of a group use 4 banks each)
+constexpr int c4_dump_bytes(int cspb) { return cspb + 128; }
+// dword offset, inside the dump area, at which halo lane t parks column q (bank-conflict free against the live lanes of its group)
+constexpr int c4_dump_off(int q, int t, int R, int cspb)
+{
+    const int TLO = R / 4, NLIVE = 16 - 2 * TLO, W = (cspb / 4) % 32, bankD = (4 * NLIVE * (cspb / 4)) % 32;
+    const int grp = t >> 3;
+    bool used[8] = {false, false, false, false, false, false, false, false};
+    for (int tt = 8 * grp; tt < 8 * grp + 8; tt++)
+        if (tt >= TLO && tt <= 15 - TLO) used[(((q * NLIVE + tt - TLO) * W) % 32) / 4] = true;
+    int k = t < TLO ? t : t - (16 - TLO);     // index among the halo lanes of this half
+    for (int slot = 0; slot < 8; slot++)
+        if (!used[slot]) {
+            if (k == 0) return ((slot * 4 - bankD) % 32 + 32) % 32;
+            k--;
+        }
+    return 0;
+}
 constexpr size_t c4_lds_bytes(int NG, int R, int NW, int nring)
 {
     const int NS = 4 * NW, RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
-    return (size_t)nring * SLOTD * 4 + (size_t)64 * (2 * 4 * NG * NS + 16) + (size_t)2 * NW * 64 * 4;
+    // ring + cost slice + (multi-wave workgroups only) the exchange area for winner keys and uniqueness counts
+    const int cspb = 2 * 4 * NG * NS + 16;
+    return (size_t)nring * SLOTD * 4 + (size_t)c4_slice_rows(R) * cspb + (R / 4 > 0 ? c4_dump_bytes(cspb) : 0) + (NW > 1 ? (size_t)2 * NW * 64 * 4 : 0);
 }
 constexpr int c4_per_cu(size_t lds, int NW)
 {
@@ -305,10 +329,11 @@ constexpr int c4_per_cu(size_t lds, int NW)
 #endif
 constexpr bool c4_refetch(int NG, int R, int NW)
 {
-    // (more than 16 one-wave workgroups per CU are not resident anyway: these shapes use 100+ VGPRs, i.e. at most 4 waves per SIMD)
+    // what the registers allow anyway (measured VGPR counts: NG <= 4 about 100-128 = 4 waves per SIMD, NG 5..7 up to 168 = 3, NG >= 8 more = 2)
+    const int cap = NG <= 4 ? 16 : NG <= 7 ? 12 : 8;
     const int with = c4_per_cu(c4_lds_bytes(NG, R, NW, 2), NW), without = c4_per_cu(c4_lds_bytes(NG, R, NW, 2 * R + 1), NW);
     // NG > 12 (nd 208 / 240) holds all 256 VGPRs: register-bound whatever the LDS says (measured: +6 % with the refetch)
-    return C4_REFETCH == 2 || (C4_REFETCH == 1 && NW == 1 && NG <= 12 && (with < 16 ? with : 16) > (without < 16 ? without : 16));
+    return C4_REFETCH == 2 || (C4_REFETCH == 1 && NW == 1 && NG <= 12 && (with < cap ? with : cap) > (without < cap ? without : cap));
 }
 
 // NW = wavefronts per workgroup.  NW = 1 is the layout described above.  With NW > 1 the waves of a workgroup work on the SAME
@@ -340,7 +365,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     constexpr int NGK = OCT ? NG / 2 : NG;      // key groups per lane
     u32* ring = (u32*)smem_raw;
     uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
-    u32* xbest = (u32*)(cs + (size_t)64 * CSPB);   // [NW][16][4] winner keys of each wave   (NW > 1 only)
+    u32* xbest = (u32*)(cs + (size_t)c4_slice_rows(R) * CSPB + (R / 4 > 0 ? c4_dump_bytes(CSPB) : 0));   // [NW][16][4] winner keys of each wave (NW > 1 only)
     u32* xcnt = xbest + NW * 64;                    // [NW][16][4] uniqueness counts of each wave
 
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -518,11 +543,24 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     // a column is valid when its whole window lies inside the tile's 64 columns (column granularity, not lane granularity: for a radius that
     // is not a multiple of 4 the outermost live lanes still produce 4 - R % 4 ... valid columns each)
     const bool writer = fin && (my_col >= R) && (my_col <= 63 - R) && (c_out >= a.cbeg) && (c_out < a.cend);
-    // cost slice rows ordered [q][t] (row = 16q + t): the stores of consecutive lanes are CSPB = 4 (mod 32) dwords apart
-    // (bank-conflict free)
-    constexpr int QSTRIDE = 16 * CSPB;
-    uint8_t* csrow_w = cs + (size_t)t * CSPB + (size_t)(4 * NG * s) * 2;
-    const uint8_t* csrow_r = cs + (size_t)(16 * qf + t) * CSPB;
+    // cost slice rows ordered [q][live lane] (row = NLIVE q + t - TLO): the stores of consecutive lanes are CSPB = 4 (mod 32) dwords apart
+    // (bank-conflict free).  The TLO lanes at either end of the row, which hold no output column, park all four of their columns in one
+    // dump row each (never read): 6 TLO rows less LDS per workgroup -- at the metric's shape what lets a 10 KB workgroup of another
+    // kernel sit next to eight matcher workgroups on a CU instead of displacing one.
+    constexpr int TLO = R / 4, NLIVE = 16 - 2 * TLO;
+    const bool live_lane = t >= TLO && t <= 15 - TLO;
+    uint8_t* const dump = cs + (size_t)4 * NLIVE * CSPB;
+    uint8_t* csw[4];
+    static_for<0, 4>([&](auto qv) {
+        constexpr int q = decltype(qv)::value;
+        int doff = 0;         // this halo lane's bank-free slot for column q (compile-time table, 2 TLO entries)
+        static_for<0, 2 * TLO>([&](auto hv) {
+            constexpr int h = decltype(hv)::value, th = h < TLO ? h : 16 - 2 * TLO + h;
+            if (t == th) doff = c4_dump_off(q, th, R, CSPB);
+        });
+        csw[q] = (live_lane ? cs + (size_t)(q * NLIVE + t - TLO) * CSPB : dump + 4 * doff) + (size_t)(4 * NG * s) * 2;
+    });
+    const uint8_t* csrow_r = live_lane ? cs + (size_t)(qf * NLIVE + t - TLO) * CSPB : dump;
 
     // Software pipeline of one iteration (row y):
     //   commit row y+R to the ring -> issue its LDS reads (A) and the global loads of row y+R+1 -> SUBTRACT row y-R-1, whose
@@ -563,8 +601,8 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         auto park = [&](auto qv, int g, P2 H0, P2 H1, bool two) {
             constexpr int q = decltype(qv)::value;
             if constexpr (C4_ABLATE & 4) return;
-            if (two) *(uint4*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint4(H0.lo, H0.hi, H1.lo, H1.hi);
-            else *(uint2*)(csrow_w + (size_t)q * QSTRIDE + g * 8) = make_uint2(H0.lo, H0.hi);
+            if (two) *(uint4*)(csw[q] + g * 8) = make_uint4(H0.lo, H0.hi, H1.lo, H1.hi);
+            else *(uint2*)(csw[q] + g * 8) = make_uint2(H0.lo, H0.hi);
         };
         auto window_sums = [&](int g, P2 (&H)[4]) {
             if constexpr (C4_ABLATE & 2) {
