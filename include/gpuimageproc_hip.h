@@ -422,6 +422,10 @@ typedef struct gip_batch_desc {
     int32_t fused_front_end;   /* 1: rectify + XSOBEL prefilter run as ONE pass raw -> prefiltered plane (gipk_rectify_xsobel) where the
                                 * configuration allows (XSOBEL, distorted camera); 0 (default): remap, then prefilter.  Bit-identical
                                 * results; the two-pass form is the faster one on MI355X, so it is the default */
+    int32_t batches_in_flight; /* 0 / 1: this batch has the device to itself.  > 1: the caller keeps that many batches in flight on streams of
+                                * its own (throughput pipelines): the matcher then leaves a quarter of every SIMD's registers to the small
+                                * kernels of the other batches instead of taking every workgroup slot it can get -- faster alone, slower as
+                                * a pipeline otherwise.  Setting matcher_stream implies > 1 */
 } gip_batch_desc;
 int gip_batch_set_maps_device(gip_handle h, int width, int height, const int16_t *map1_l, const uint16_t *map2_l,
                               const int16_t *map1_r, const uint16_t *map2_r);

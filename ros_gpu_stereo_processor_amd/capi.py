@@ -82,7 +82,7 @@ class PointCloud2Msg(C.Structure):
 class BatchDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32),
                 ("left_raw", C.c_void_p), ("right_raw", C.c_void_p), ("disparity", C.c_void_p), ("disparity_f32", C.c_void_p),
-                ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p), ("fused_front_end", C.c_int32)]
+                ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p), ("fused_front_end", C.c_int32), ("batches_in_flight", C.c_int32)]
 
 
 class StreamerConfig(C.Structure):

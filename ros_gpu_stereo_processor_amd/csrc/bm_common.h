@@ -30,6 +30,7 @@ struct BmLaunchCtx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;     // recorded around the matcher kernel, on the stream it is launched on
     hipStream_t matcher_stream = nullptr;        // launch the matcher here instead of the caller's stream ...
     hipEvent_t fork = nullptr, join = nullptr;   // ... fenced by these two events (required when matcher_stream is set)
+    bool co_scheduled = false;                   // kernels of other batches run next to this launch (gip_batch_desc::batches_in_flight > 1)
 };
 
 // k_stereobm_c4.hip: column-sum matcher, every output column.  Returns GIP_OK and sets *handled when a kernel

@@ -1237,6 +1237,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     BmLaunchCtx mctx;
     mctx.ev0 = ev[0];
     mctx.ev1 = ev[1];
+    mctx.co_scheduled = d->batches_in_flight > 1 || (d->matcher_stream && (hipStream_t)d->matcher_stream != st);
     if (d->matcher_stream && (hipStream_t)d->matcher_stream != st) {
         if (!h->match_fork) {
             H_HIP(h, hipEventCreateWithFlags(&h->match_fork, hipEventDisableTiming));

@@ -837,7 +837,7 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
 {
     // measurement knob: GIP_C4_LDS_PAD=n allocates n more bytes of LDS per workgroup (fewer matcher workgroups per CU; read once)
     static const int env_pad = [] { const char* e = getenv("GIP_C4_LDS_PAD"); return e ? atoi(e) : 0; }();
-    const size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1) + (size_t)(env_pad > 0 ? env_pad : 0);
+    size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1) + (size_t)(env_pad > 0 ? env_pad : 0);
     const int ncols = a.cend - a.cbeg;
     const int ntiles = (ncols + (64 - 2 * R) - 1) / (64 - 2 * R);
     const int nrows = a.row1 - a.row0;
@@ -866,6 +866,28 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
     }
     if (per_cu > 4 * vgpr_waves / NW) per_cu = 4 * vgpr_waves / NW;
     if (per_cu < 1) per_cu = 1;
+    // Co-scheduled (other batches' kernels run next to this launch): a matcher that fills every SIMD's register file (4 waves x 128 VGPRs at
+    // nd 256 / block 21) leaves no room for a single wave of the small kernels that feed it and take its results -- they then run only in the
+    // cracks between matcher workgroups and the STEP gets longer although the matcher gets shorter (4 instead of 3 workgroups per CU: matcher
+    // -10 %, pipeline -3.4 %; capped: pipeline +1.3 %).  So: never more than 90 % of the CU's registers, by padding the LDS request just far
+    // enough that one workgroup less fits (the rest of the LDS stays free for the other kernels).  Shapes below that line are left alone:
+    // a stricter rule (always leave 128 registers per SIMD) cost nd 192 / block 15 11 % and nd 48 / block 19 7 % (tools/bench_ab.sh).
+    static int vgpr_alloc = 0;
+    if (vgpr_alloc == 0) {
+        hipFuncAttributes fa;
+        vgpr_alloc = 128;
+        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW, RF>) == hipSuccess && fa.numRegs > 0) vgpr_alloc = (fa.numRegs + 7) & ~7;
+    }
+    if (ctx && ctx->co_scheduled) {
+        int cap = per_cu;
+        while (cap > 1 && cap * NW * vgpr_alloc * 10 > 4 * 512 * 9) cap--;
+        if (cap < per_cu) {
+            per_cu = cap;
+            // the SMALLEST request of which cap + 1 no longer fit
+            const size_t granule = 1280, want = ((size_t)160 * 1024 / (cap + 1)) / granule * granule + granule;
+            if (want > sh) sh = want;
+        }
+    }
 #ifdef C4_FIXED_CHUNKS
     int nch = C4_FIXED_CHUNKS;
 #else
@@ -925,7 +947,7 @@ template <int NG, int R, int NW>
 int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
     if constexpr (c4_refetch(NG, R, NW)) {
-        const bool pipelined = ctx && ctx->matcher_stream && ctx->matcher_stream != st;
+        const bool pipelined = ctx && (ctx->co_scheduled || (ctx->matcher_stream && ctx->matcher_stream != st));
         if (!pipelined) return launch_c4_rf<NG, R, NW, true>(a, batch, st, ctx);
     }
     return launch_c4_rf<NG, R, NW, false>(a, batch, st, ctx);

@@ -17,7 +17,7 @@ ENCODINGS = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bayer_rggb8": 3, "bayer_bggr8": 
 
 class BatchPipeline:
     def __init__(self, width, height, calib, params, batch, encoding="mono8", outputs=capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD,
-                 device=0, max_speckle_size=0, max_speckle_diff=0.0, want_f32=True, fused_front_end=False):
+                 device=0, max_speckle_size=0, max_speckle_diff=0.0, want_f32=True, fused_front_end=False, batches_in_flight=1):
         self.w, self.h, self.batch, self.encoding = width, height, batch, encoding
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
@@ -28,6 +28,7 @@ class BatchPipeline:
         self.proc.setMaxSpeckleDiff(max_speckle_diff)
         self.outputs = outputs
         self.fused_front_end = fused_front_end
+        self.batches_in_flight = batches_in_flight     # how many pipelines like this one the caller keeps busy on this device
         self.disparity = torch.empty((batch, height, width), dtype=torch.int16, device=self.dev)
         self.disparity_f32 = torch.empty((batch, height, width), dtype=torch.float32, device=self.dev) if want_f32 else None
         self.pointcloud = torch.empty((batch, height, width, 32), dtype=torch.uint8, device=self.dev) if outputs & capi.TOPIC_POINTCLOUD else None
@@ -64,6 +65,7 @@ class BatchPipeline:
         d.pointcloud = self.pointcloud.data_ptr() if self.pointcloud is not None else None
         d.matcher_stream = matcher_stream.cuda_stream if matcher_stream is not None else None
         d.fused_front_end = 1 if self.fused_front_end else 0
+        d.batches_in_flight = int(self.batches_in_flight)
         capi.check(self._lib.gip_batch_run(self.proc.handle, C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.proc.handle)
 
     def timing_reset(self):
