@@ -23,12 +23,16 @@
 //     the columns whose window lies inside the tile, 4t+q in [r, 63-r]; tiles advance by 64-2r columns.
 //   * BORDER tiles (the clamped-column rule of OpenCV applies somewhere in the tile) keep the four column sums V0..V3 themselves
 //     (one live reference byte per v_mqsad, byte position = clamped column) and form the window sums column-wise.
-//   * Winner-take-all: per 4-disparity group a packed min and one 32-bit key (cost << 8 | group); quarters are merged with
-//     two xor-shuffles.  The row's cost slice is parked in LDS; lane (s,t) then finalises pixel 4t+s: exact winner inside the
-//     group, sub-pixel neighbours, texture test and the uniqueness test (count of groups <= threshold vs the groups that
-//     touch the winner, then an exact check of those 12 costs).
-//   * Prefiltered rows are staged in an LDS ring of 2r+1 rows by the wave itself with aligned dword loads issued one row
-//     ahead (register prefetch), so global latency overlaps the SAD work.
+//   * Winner-take-all: per 8-disparity group (4 when NG is odd) a packed min and one 32-bit key (cost << 8 | group); the quarters are
+//     merged on the VALU with v_permlane16_swap / v_permlane32_swap (quarters_reduce).  The row's cost slice is parked in LDS (one row
+//     per live lane and column, the halo lanes into bank-free dump slots); lane (s,t) then finalises pixel 4t+s: exact winner inside the
+//     group, sub-pixel neighbours, texture test and the uniqueness test (count of groups <= threshold vs the groups that touch the
+//     winner, then an exact check of those costs).
+//   * Prefiltered rows are staged by the wave itself with aligned dword loads issued one row ahead (register prefetch), so global latency
+//     overlaps the SAD work -- into an LDS ring of 2r+1 rows, or (refetch form, chosen at launch for one-wave large-block shapes that have the
+//     device to themselves) into two slots, the leaving row being loaded a second time.
+//   * The launcher (launch_c4_rf) picks the row chunking from the kernel's LDS / VGPR footprint and, when the caller declares other batches
+//     in flight, leaves room for their kernels.
 #pragma once
 #include "gip_internal.h"
 #include "bm_common.h"
