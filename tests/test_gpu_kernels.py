@@ -432,3 +432,28 @@ def test_bm_fuzz_bit_exact(gpu, oracle, seed):
     exp = oracle.stereobm(l, r, oracle.bm_params(**kw))
     got = _n(K.stereobm(_t(l, gpu), _t(r, gpu), K.bm_params(**kw)))
     assert np.array_equal(got, exp), case
+
+
+def test_bm_result_independent_of_row_chunking(gpu, oracle):
+    """The matcher cuts every tile column into row chunks chosen from the device and the kernel's footprint (launch_c4_rf); a chunk starts with
+    2r warm-up rows of its own, so the result must not depend on where the cuts fall.  GIP_C4_CHUNKS forces the count (read once per process):
+    run the same frame in child processes with 1 and 5 chunks and compare with this process (automatic choice) and with the oracle."""
+    import hashlib, subprocess, sys, os
+    from ros_gpu_stereo_processor_amd import kernels as K
+    w, h, nd, block = 600, 200, 64, 11
+    l, r, _ = synth.rectified_pair(w, h, nd, seed=4242)
+    kw = dict(block_size=block, num_disparities=nd, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1)
+    got = _n(K.stereobm(_t(l, gpu), _t(r, gpu), K.bm_params(**kw)))
+    assert np.array_equal(got, oracle.stereobm(l, r, oracle.bm_params(**kw)))
+    want = hashlib.sha256(got.tobytes()).hexdigest()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from ros_gpu_stereo_processor_amd import kernels as K, synth\n"
+            "l, r, _ = synth.rectified_pair(%d, %d, %d, seed=4242)\n"
+            "d = K.stereobm(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), K.bm_params(**%r))\n"
+            "print(hashlib.sha256(d.cpu().numpy().tobytes()).hexdigest())\n") % (root, w, h, nd, kw)
+    for chunks in ("1", "5"):
+        env = dict(os.environ, GIP_C4_CHUNKS=chunks)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1] == want, chunks
