@@ -24,6 +24,7 @@ bool gip_bm_c4_can(const BmArgs& a)
     if ((a.pitch & 3) || ((uintptr_t)a.L & 3) || ((uintptr_t)a.R & 3) || (a.img_bs & 3)) return false;
     if (a.cend <= a.cbeg) return false;
     if (a.ndisp < 16 || a.ndisp > 256 || a.ndisp % 16) return false;
+    if (a.uniq >= 200) return false;   // the kernel's multiply-shift form of  ms * uniq / 100  is exact below 200 (OpenCV's range is 5..15)
     return a.wsz2 >= 2 && a.wsz2 <= 15;
 }
 

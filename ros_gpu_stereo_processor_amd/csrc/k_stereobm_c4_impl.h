@@ -512,6 +512,13 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         else asm volatile("" ::: "memory");
     };
 
+    // uniqueness threshold  thr = ms + ms * uniq / 100  (integer division) without a 32-bit multiply and divide: with K = ceil(uniq * 2^23 / 100)
+    // (ms * K) >> 23 == ms * uniq / 100 for every ms < 2^16 and uniq < 200 (the error term ms * delta / 2^23 is below 2^-7 and a fraction of
+    // x / 100 is at most 0.99; checked exhaustively in tests/test_capi_symbols.py).  Both factors are masked to 24 bits, so the compiler emits
+    // v_mul_u32_u24 + v_mul_hi_u32_u24 + v_alignbit_b32 instead of v_mul_lo_u32, v_mul_hi_u32 (magic division), shift and add.
+    const u32 UK = (u32)((((u64)(u32)a.uniq << 23) + 99u) / 100u) & 0xFFFFFFu;     // gip_bm_c4_can: uniq < 200
+    auto uniq_thr = [&](u32 ms) -> u32 { return ms + (u32)(((u64)(ms & 0xFFFFFFu) * (u64)UK) >> 23); };
+
     // ---- warm-up: rows ya-R .. ya+R-1 enter the window
     if constexpr (RF) {
         prefetch(ya - R);
@@ -682,7 +689,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const u32 ms = best[q] >> 8;
-                const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
+                const u32 thr = uniq_thr(ms);
                 u32 c = 0;
 #pragma unroll
                 for (int g = 0; g < NGK; g++) c += (gmin[q][g] <= thr) ? 1u : 0u;
@@ -753,7 +760,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             if (a.uniq > 0) {
                 // exact part of the uniqueness test on the 12 costs, packed: "some u16 of x is <= thr"  <=>  pk_min(x, T1) != T1
                 // with T1 = thr + 1 in both halves
-                const u32 thr = ms + (ms * (u32)a.uniq) / 100u;
+                const u32 thr = uniq_thr(ms);
                 const u32 t1 = umin(thr + 1u, 0xFFFFu), T1 = t1 | (t1 << 16);
                 // key groups among the three read whose minimum is <= thr (what the count over ALL key groups must not exceed)
                 int touch_le;
@@ -778,7 +785,9 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 const u32 ad = p > n ? p - n : n - p;
                 const u32 den = p + n - 2u * ms + ad;
                 const u32 num = ad << 8;
-                u32 q0 = (u32)((float)num * __frcp_rn((float)den));
+                // v_rcp_f32 (1 ulp) instead of the correctly rounded reciprocal (ten instructions): the quotient is at most 128, so q0 is within
+                // one of the exact value and the correction step below repairs either direction
+                u32 q0 = (u32)((float)num * __builtin_amdgcn_rcpf((float)den));
                 const int r = (int)(num - q0 * den);
                 q0 += (r >= (int)den) ? 1u : 0u;
                 q0 -= (r < 0) ? 1u : 0u;

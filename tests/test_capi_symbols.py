@@ -128,3 +128,14 @@ def test_camera_info_binning_and_roi_tables(built_lib, calib):
     assert np.array_equal(g1, f1) and np.array_equal(g2, f2)
     bad = camera_info(W, H, c["K"], c["D"], c["R"], c["P"], roi=(W - 10, 0, 64, 64))
     assert L.gip_build_rectify_maps(ctypes.byref(bad), g1.ctypes.data, g2.ctypes.data) == capi.ERR_INVALID_ARG
+
+
+def test_uniqueness_threshold_multiply_shift_identity():
+    """k_stereobm_c4_impl.h computes  ms * uniq / 100  as  (ms * K) >> 23  with K = ceil(uniq * 2^23 / 100): exact for every minimum cost the u16
+    path can produce and every uniqueness ratio the fast path accepts (gip_bm_c4_can: uniq < 200)."""
+    import numpy as np
+    ms = np.arange(65536, dtype=np.uint64)
+    for u in range(200):
+        K = (u * (1 << 23) + 99) // 100
+        assert K < (1 << 24)
+        assert np.array_equal((ms * u) // 100, (ms * K) >> 23), u
