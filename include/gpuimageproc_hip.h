@@ -384,6 +384,21 @@ int gipk_speckle_set_sizes(void *scratch, size_t scratch_bytes, int w, int h, in
 int gipk_speckle_apply(int16_t *disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, void *scratch,
                        size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream);
 
+/* Device-side merge of the components that cross tile borders (row-tile split; no host round trip):
+ *   border_record  after gipk_speckle_label: this tile's record of its first and last row (value, link to the component's canonical border
+ *                  pixel, tile-local component size: gipk_speckle_border_record_bytes(w) = 20 bytes per column, rounded up to 256) and
+ *                  border_roots[2 w], the tile-local root of every border pixel;
+ *   border_merge   `records` = the records of ALL n_tiles tiles, contiguous in tile order, on this device (gathered by peer copies or an
+ *                  all-gather); unites the components that touch across the borders and overwrites the sizes of tile `tile`'s own border
+ *                  components with the size of the whole component; `work` >= gipk_speckle_border_work_bytes(w, n_tiles).
+ * gipk_speckle_apply then erases exactly what cv::filterSpeckles erases on the full frame. */
+size_t gipk_speckle_border_record_bytes(int w);
+size_t gipk_speckle_border_work_bytes(int w, int n_tiles);
+int gipk_speckle_border_record(const int16_t *disp, size_t disp_pitch, int w, int h, void *scratch, size_t scratch_bytes, void *record,
+                               int32_t *border_roots, gip_stream stream);
+int gipk_speckle_border_merge(const void *records, int n_tiles, int tile, int w, int h, int new_val, int max_diff, void *scratch,
+                              size_t scratch_bytes, const int32_t *border_roots, void *work, size_t work_bytes, gip_stream stream);
+
 /* reprojectImageTo3D on the float disparity (missing = the image minimum, i.e. `missing_value`) */
 int gipk_reproject_to_3d(const float *disp, size_t disp_pitch, float *xyz, size_t xyz_pitch, int w, int h, const double Q[16],
                          float missing_value, int handle_missing, int batch, size_t disp_bstride, size_t xyz_bstride,
@@ -400,6 +415,10 @@ int gipk_disparity_to_pointcloud2(const int16_t *disp, size_t disp_pitch, const 
 int gipk_disparity_outputs(const int16_t *disp, size_t disp_pitch, const uint8_t *color, size_t color_pitch, int color_cn, float *f32_out,
                            uint8_t *pc_out, int w, int h, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
                            size_t disp_bstride, size_t color_bstride, gip_stream stream);
+/* the same for rows [y_origin, y_origin + h) of a larger frame (a row tile): only the row term of the reprojection sees y_origin */
+int gipk_disparity_outputs_rows(const int16_t *disp, size_t disp_pitch, const uint8_t *color, size_t color_pitch, int color_cn, float *f32_out,
+                                uint8_t *pc_out, int w, int h, int y_origin, const double Q[16], double cx_l, double cx_r, int min_disparity,
+                                int batch, size_t disp_bstride, size_t color_bstride, gip_stream stream);
 int gipk_draw_color_disp(const int16_t *disp, size_t disp_pitch, uint8_t *bgra, size_t bgra_pitch, int w, int h, int ndisp,
                          int batch, size_t disp_bstride, size_t bgra_bstride, gip_stream stream);
 
@@ -441,6 +460,62 @@ int gip_batch_timing_read(gip_handle h, double *bm_ms_sum, double *total_ms_sum,
  * conversion, rectify, prefilter, matcher, L/R check) -- the stages whose compulsory HBM traffic is the 16 bytes per pixel of
  * SURVEY.md section 8(d) */
 int gip_batch_timing_read_spans(gip_handle h, double *bm_ms_sum, double *total_ms_sum, double *remap_sad_ms_sum, int *runs);
+
+/* ================================================================== row-tile split of ONE large frame (gip_rowsplit_*)
+ * BASELINE configs[4]: a 4096x2160 frame cut into N row tiles, one per GPU.  The reference launches every stage once per frame on one
+ * GPU and then waits (reference src/GPUStereoProcessor.cpp:283 block_matcher_gpu_->compute, src/StereoProcessor.cpp:284
+ * waitForAllStreams); here ONE process owns N processor handles -- one per tile, each on its own device (tiles share devices when there
+ * are fewer devices than tiles) -- and every buffer of the steady state is allocated at open:
+ *   tile t owns output rows [y0, y1) and works on the extended rows [e0, e1) = its own rows + the halo (block radius + 1 for XSOBEL;
+ *   + the prefilter radius for NORMALIZED_RESPONSE) of the RECTIFIED images;
+ *   front   rectify the tile's rows of both eyes (the raw frame is resident on every tile's device) into ONE buffer whose rows interleave
+ *           the two eyes, so that the halo rows of both eyes are one contiguous block;
+ *   halo    one hipMemcpyPeerAsync per neighbour pulls that block (over xGMI between devices; a device-to-device copy when the tiles
+ *           share a device) -- or, halo_mode 1, every tile rectifies its own halo rows and nothing is exchanged;
+ *   match   prefilter + SAD matcher + L/R check on the extended tile (row-local: the tile's own rows equal the full frame's bit for bit);
+ *   speckle every tile labels its own rows, publishes its border record (gipk_speckle_border_record), pulls the records of the other
+ *           tiles and merges on the device (gipk_speckle_border_merge); then erases small components and writes float disparity and
+ *           PointCloud2 records for its rows.
+ * One host thread per tile enqueues that tile's work (host_threads); results stay on the tiles' devices (gip_rowsplit_outputs_device) or
+ * are stitched into host memory (gip_rowsplit_download).  No CPU fallback, no host round trip in the steady state. */
+typedef struct gip_rowsplit_s *gip_rowsplit;
+typedef struct gip_rowsplit_config {
+    int32_t width, height;
+    int32_t encoding;        /* as gip_batch_desc::encoding */
+    uint32_t outputs;        /* GIP_TOPIC_DISPARITY (float disparity) and/or GIP_TOPIC_POINTCLOUD; the int16 map is always produced */
+    int32_t n_tiles;         /* 1..16 */
+    int32_t devices[16];     /* HIP device of tile t; a negative entry = t mod gip_device_count() */
+    int32_t halo_mode;       /* 0: neighbours exchange rectified halo rows (hipMemcpyPeerAsync); 1: every tile rectifies its halo rows itself */
+    int32_t host_threads;    /* 0: one enqueueing host thread per tile when n_tiles > 1; 1: the calling thread enqueues everything */
+} gip_rowsplit_config;
+/* per-tile GPU time of the last run (ms, hipEvents on the tile's stream): front = colour + rectify, halo = waiting for and pulling the
+ * neighbours' rows, match = prefilter + matcher + L/R check + speckle labelling + border record, gather = waiting for and pulling the
+ * other tiles' records, post = merge + erase + float disparity + cloud */
+typedef struct gip_rowsplit_timing {
+    float front_ms, halo_ms, match_ms, gather_ms, post_ms, total_ms;
+} gip_rowsplit_timing;
+
+int gip_rowsplit_open(const gip_camera_info *left, const gip_camera_info *right, const gip_bm_params *params, int max_speckle_size,
+                      double max_speckle_diff, const gip_rowsplit_config *cfg, gip_rowsplit *out);
+int gip_rowsplit_close(gip_rowsplit rs);
+const char *gip_rowsplit_last_error(gip_rowsplit rs);
+/* the plan: own rows [y0, y1), extended rows [e0, e1), device of a tile */
+int gip_rowsplit_plan(gip_rowsplit rs, int tile, int *y0, int *y1, int *e0, int *e1, int *device);
+/* the raw frame as resident on tile `tile`'s device (full frame, tight rows); must stay valid until the run that uses it has finished */
+int gip_rowsplit_set_inputs_device(gip_rowsplit rs, int tile, const uint8_t *left_raw, const uint8_t *right_raw);
+/* host frame -> every tile's device (pinned staging inside; asynchronous on the tiles' streams); step 0 = tight rows */
+int gip_rowsplit_upload(gip_rowsplit rs, const void *left_raw, const void *right_raw, size_t step);
+/* enqueue one frame on every tile's stream (returns when everything is enqueued) / wait for it */
+int gip_rowsplit_run(gip_rowsplit rs);
+int gip_rowsplit_wait(gip_rowsplit rs);
+/* one frame with the tiles run ONE AFTER THE OTHER, each with its device to itself (what a rank on its own GPU sees); synchronous.
+ * Fills timing[n_tiles] (may be NULL); the frame's results are the same as gip_rowsplit_run's. */
+int gip_rowsplit_run_serial(gip_rowsplit rs, gip_rowsplit_timing *timing);
+int gip_rowsplit_last_timing(gip_rowsplit rs, int tile, gip_rowsplit_timing *out);
+/* results of the tile's own rows on its device: int16 x16 map (pitch = width), float image and 32-byte records (NULL when not requested) */
+int gip_rowsplit_outputs_device(gip_rowsplit rs, int tile, const int16_t **disparity, const float **disparity_f32, const uint8_t **pointcloud);
+/* stitched frame into host memory (any of the three may be NULL); synchronous */
+int gip_rowsplit_download(gip_rowsplit rs, int16_t *disparity, float *disparity_f32, uint8_t *pointcloud);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,15 @@ class StreamerResult(C.Structure):
                 ("disparity_f32", C.c_void_p), ("pointcloud", C.c_void_p)]
 
 
+class RowSplitConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32), ("n_tiles", C.c_int32),
+                ("devices", C.c_int32 * 16), ("halo_mode", C.c_int32), ("host_threads", C.c_int32)]
+
+
+class RowSplitTiming(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("front_ms", "halo_ms", "match_ms", "gather_ms", "post_ms", "total_ms")]
+
+
 STREAMER_CB = C.CFUNCTYPE(None, C.POINTER(StreamerResult), C.c_void_p)
 IMAGE_CB = C.CFUNCTYPE(None, C.POINTER(ImageMsg), C.c_void_p)
 DISPARITY_CB = C.CFUNCTYPE(None, C.POINTER(DisparityMsg), C.c_void_p)
@@ -197,6 +206,23 @@ PROTOTYPES = {
     "gip_streamer_delivered": (C.c_uint64, [_vp]),
     "gip_streamer_close": (_i, [_vp]),
     "gip_streamer_last_error": (C.c_char_p, [_vp]),
+    "gipk_disparity_outputs_rows": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp, _i, _i, _i, C.POINTER(_d), _d, _d, _i, _i, _sz, _sz, _vp]),
+    "gipk_speckle_border_record_bytes": (_sz, [_i]),
+    "gipk_speckle_border_work_bytes": (_sz, [_i, _i]),
+    "gipk_speckle_border_record": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "gipk_speckle_border_merge": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "gip_rowsplit_open": (_i, [C.POINTER(CameraInfo), C.POINTER(CameraInfo), C.POINTER(BMParams), _i, _d, C.POINTER(RowSplitConfig), C.POINTER(_vp)]),
+    "gip_rowsplit_close": (_i, [_vp]),
+    "gip_rowsplit_last_error": (C.c_char_p, [_vp]),
+    "gip_rowsplit_plan": (_i, [_vp, _i] + [C.POINTER(_i)] * 5),
+    "gip_rowsplit_set_inputs_device": (_i, [_vp, _i, _vp, _vp]),
+    "gip_rowsplit_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "gip_rowsplit_run": (_i, [_vp]),
+    "gip_rowsplit_wait": (_i, [_vp]),
+    "gip_rowsplit_run_serial": (_i, [_vp, C.POINTER(RowSplitTiming)]),
+    "gip_rowsplit_last_timing": (_i, [_vp, _i, C.POINTER(RowSplitTiming)]),
+    "gip_rowsplit_outputs_device": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "gip_rowsplit_download": (_i, [_vp, _vp, _vp, _vp]),
     "gip_batch_timing_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
     "gip_batch_timing_read_spans": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
 }

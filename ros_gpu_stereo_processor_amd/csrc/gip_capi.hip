@@ -24,6 +24,7 @@
 #include "gip_internal.h"
 #include "gip_model.h"
 #include "bm_common.h"
+#include "gip_handle_view.h"
 
 // ------------------------------------------------------------------------------------------------ error text
 static thread_local char g_hip_err[512] = "";
@@ -486,6 +487,32 @@ int gip_get_rectify_maps(gip_handle h, int side, int16_t* map1, uint16_t* map2)
 }
 
 // ------------------------------------------------------------------------------------------------ upload / download
+}  // extern "C"
+
+int gip_handle_view(gip_handle h, GipHandleView* v)
+{
+    if (!h || !v) return GIP_ERR_INVALID_ARG;
+    if (!h->model.initialised || !h->d_map1[0]) return fail(h, GIP_ERR_NOT_INITIALISED, "stereo model not initialised");
+    v->device = h->device;
+    v->width = h->map_w;
+    v->height = h->map_h;
+    for (int i = 0; i < 2; i++) {
+        v->map1[i] = h->d_map1[i];
+        v->map2[i] = h->d_map2[i];
+    }
+    v->distorted[0] = h->model.left.distorted;
+    v->distorted[1] = h->model.right.distorted;
+    std::memcpy(v->Q, h->model.Q, sizeof v->Q);
+    v->cx_l = h->model.left.cx();
+    v->cx_r = h->model.right.cx();
+    v->params = h->params;
+    v->max_speckle_size = h->max_speckle_size;
+    v->max_speckle_diff = h->max_speckle_diff;
+    return GIP_OK;
+}
+
+extern "C" {
+
 int gip_upload_mat(gip_handle h, int slot, const void* data, int rows, int cols, size_t step, int type, const char* encoding)
 {
     H_CHECK(h);

@@ -565,6 +565,88 @@ __global__ void __launch_bounds__(256) k_spk_set_sizes(SpkScratch S, const int* 
     if (i < n) S.csize[roots[i]] = sizes[i];
 }
 
+// ---- row-tile split (BASELINE configs[4]): components that cross tile borders, merged ON THE DEVICE --------------------------------
+// A frame cut into N row tiles is labelled tile by tile (gipk_speckle_label on every tile's own rows).  What the tiles must agree on is
+// the size of the components that continue across a border.  Each tile publishes a BORDER RECORD of its first and last row -- per pixel
+// p in [0, 2w) (p < w: first row, else last row): the disparity value, `link` = the smallest border-pixel index of the same component
+// in this tile (-1: invalid pixel; link[p] == p marks the component's canonical border pixel) and the component's tile-local size --
+// 20 bytes per image column.  The records of all tiles are brought together (hipMemcpyPeerAsync / an all-gather), and every tile runs
+// k_spk_border_merge on them: a union-find over the 2wN border pixels (pixels of one component of one tile are pre-linked through
+// `link`; pixels facing each other across a border are united when cv::filterSpeckles' rule connects them), component totals at the
+// roots, and the sizes of the tile's OWN border components overwritten with the total of the whole component -- k_spk_apply then
+// erases exactly what the filter on the full frame erases.  No host round trip, no host union-find.
+constexpr int BRD_TPB = 1024;
+__host__ __device__ inline size_t spk_border_record_bytes(int w) { return ((size_t)20 * w + 255) / 256 * 256; }
+__device__ __forceinline__ const int16_t* brd_val(const uint8_t* rec) { return (const int16_t*)rec; }
+__device__ __forceinline__ const int* brd_link(const uint8_t* rec, int w) { return (const int*)(rec + (size_t)4 * w); }
+__device__ __forceinline__ const int* brd_size(const uint8_t* rec, int w) { return (const int*)(rec + (size_t)12 * w); }
+
+// one workgroup; S = the labelled tile (after k_spk_sizes); roots[2w] (out) = tile-local root node of every border pixel, -1 = invalid
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_record(const int16_t* __restrict__ disp, size_t dpitch, SpkScratch S, int w, int h, uint8_t* __restrict__ rec,
+                                                                int* __restrict__ roots)
+{
+    int* canon = (int*)S.joinlist;          // one slot per node; the join lists are dead once k_spk_cross has run
+    const int n2 = 2 * w;
+    for (int p = threadIdx.x; p < n2; p += BRD_TPB) {
+        const int row = p < w ? 0 : h - 1, x = p < w ? p : p - w;
+        const unsigned ord = S.ord16[(size_t)row * w + x];
+        int root = -1;
+        if (ord != 0xFFFFu) {
+            const int r1 = S.parent[(size_t)row * w + ord];
+            root = S.parent[r1];            // k_spk_sizes left the global root in every strip-local root
+            canon[root] = 0x7FFFFFFF;
+        }
+        roots[p] = root;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n2; p += BRD_TPB) {
+        const int root = roots[p];
+        if (root >= 0) __hip_atomic_fetch_min(&canon[root], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int16_t* val = (int16_t*)rec;
+    int* link = (int*)(rec + (size_t)4 * w);
+    int* size = (int*)(rec + (size_t)12 * w);
+    for (int p = threadIdx.x; p < n2; p += BRD_TPB) {
+        const int row = p < w ? 0 : h - 1, x = p < w ? p : p - w;
+        const int root = roots[p];
+        val[p] = disp[(size_t)row * dpitch + x];
+        link[p] = root >= 0 ? __hip_atomic_load(&canon[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        size[p] = root >= 0 ? S.csize[root] : 0;
+    }
+}
+
+// one workgroup; recs = the records of all n_tiles tiles (rec_stride bytes apart), `me` = the tile whose sizes are patched (S, roots);
+// par / tot = 2 w n_tiles ints of scratch each
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_merge(const uint8_t* __restrict__ recs, size_t rec_stride, int n_tiles, int me, int w, int new_val, int max_diff,
+                                                               SpkScratch S, const int* __restrict__ roots, int* par, int* tot)
+{
+    const int n2 = 2 * w, N = n_tiles * n2;
+#pragma unroll 4
+    for (int g = threadIdx.x; g < N; g += BRD_TPB) {
+        const int t = g / n2, p = g - t * n2;
+        const int lk = brd_link(recs + t * rec_stride, w)[p];
+        par[g] = lk >= 0 ? t * n2 + lk : g;
+        tot[g] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (n_tiles - 1) * w; i += BRD_TPB) {
+        const int b = i / w, x = i - b * w;
+        const int vb = brd_val(recs + b * rec_stride)[w + x], vt = brd_val(recs + (b + 1) * rec_stride)[x];
+        if (spk_conn(vb, vt, new_val, max_diff)) uf_union(par, b * n2 + w + x, (b + 1) * n2 + x);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int g = threadIdx.x; g < N; g += BRD_TPB) {
+        const int t = g / n2, p = g - t * n2;
+        if (brd_link(recs + t * rec_stride, w)[p] == p) atomicAdd(&tot[uf_find(par, g)], brd_size(recs + t * rec_stride, w)[p]);
+    }
+    __syncthreads();
+    const int* mylink = brd_link(recs + me * rec_stride, w);
+    for (int p = threadIdx.x; p < n2; p += BRD_TPB)
+        if (mylink[p] == p) S.csize[roots[p]] = __hip_atomic_load(&tot[uf_find(par, me * n2 + p)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------- reprojection / cloud
 struct QMat { double q[16]; };
 
@@ -617,7 +699,7 @@ __global__ void k_pack_pc2(const float* __restrict__ xyz, size_t xpitch, const u
 template <int CN>
 __global__ void k_disp_outputs(const int16_t* __restrict__ disp, size_t dpitch, const uint8_t* __restrict__ col, size_t cpitch,
                                float* __restrict__ f32out, uint8_t* __restrict__ pc, int w, int h, QMat Q, float alpha, float beta, int filtered,
-                               size_t dbs, size_t cbs, size_t fbs, size_t obs)
+                               size_t dbs, size_t cbs, size_t fbs, size_t obs, int y_org)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
@@ -628,8 +710,9 @@ __global__ void k_disp_outputs(const int16_t* __restrict__ disp, size_t dpitch, 
     if (f32out) ((float*)((uint8_t*)f32out + blockIdx.z * fbs))[(size_t)y * w + x] = df;
     if (!pc) return;
     double d = df;
-    double qx = q[1] * y + q[3] + q[0] * x, qy = q[5] * y + q[7] + q[4] * x;
-    double qz = q[9] * y + q[11] + q[8] * x, qw = q[13] * y + q[15] + q[12] * x;
+    const int yf = y + y_org;      // row of the full frame (row-tile split: the tile holds rows [y_org, y_org + h))
+    double qx = q[1] * yf + q[3] + q[0] * x, qy = q[5] * yf + q[7] + q[4] * x;
+    double qz = q[9] * yf + q[11] + q[8] * x, qw = q[13] * yf + q[15] + q[12] * x;
     double iW = 1. / (qw + q[14] * d);
     double X = (qx + q[2] * d) * iW, Y = (qy + q[6] * d) * iW, Z = (qz + q[10] * d) * iW;
     if (d16 == filtered) Z = 10000.;
@@ -649,7 +732,7 @@ constexpr int OUT_ROWS = 1;   // 4 rows per thread (64x4 blocks) halved the stor
 template <int CN>
 __global__ void k_disp_outputs_sq(const int16_t* __restrict__ disp, size_t dpitch, const uint8_t* __restrict__ col, size_t cpitch,
                                   float* __restrict__ f32out, uint8_t* __restrict__ pc, int w, int h, QMat Q, float alpha, float beta, int filtered,
-                                  size_t dbs, size_t cbs, size_t fbs, size_t obs)
+                                  size_t dbs, size_t cbs, size_t fbs, size_t obs, int y_org)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = (blockIdx.y * blockDim.y + threadIdx.y) * OUT_ROWS;
     if (x >= w || y0 >= h) return;
@@ -678,7 +761,7 @@ __global__ void k_disp_outputs_sq(const int16_t* __restrict__ disp, size_t dpitc
         if (f32out) ((float*)((uint8_t*)f32out + blockIdx.z * fbs))[(size_t)y * w + x] = df;
         if (!pc) continue;
         const double d = df;
-        const double qy = q[5] * y + q[7];
+        const double qy = q[5] * (y + y_org) + q[7];
         const double iW = 1. / (q[15] + q[14] * d);
         const double X = qx * iW, Y = qy * iW;
         double Z = q[11] * iW;
@@ -845,6 +928,38 @@ int gipk_speckle_set_sizes(void* scratch, size_t scratch_bytes, int w, int h, in
     return GIP_OK;
 }
 
+size_t gipk_speckle_border_record_bytes(int w) { return w > 0 ? spk_border_record_bytes(w) : 0; }
+size_t gipk_speckle_border_work_bytes(int w, int n_tiles) { return (w > 0 && n_tiles > 0) ? (size_t)16 * w * n_tiles + 256 : 0; }
+
+int gipk_speckle_border_record(const int16_t* disp, size_t disp_pitch, int w, int h, void* scratch, size_t scratch_bytes, void* record, int32_t* border_roots,
+                               gip_stream stream)
+{
+    GIPK_ARGCHECK(disp && record && border_roots && w > 0 && h > 0 && disp_pitch % 2 == 0 && ((uintptr_t)record & 3) == 0);
+    SpkScratch S;
+    int rc = spk_carve(scratch, scratch_bytes, w, h, 1, &S);
+    if (rc != GIP_OK) return rc;
+    hipLaunchKernelGGL(k_spk_border_record, dim3(1), dim3(BRD_TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, S, w, h, (uint8_t*)record, border_roots);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
+int gipk_speckle_border_merge(const void* records, int n_tiles, int tile, int w, int h, int new_val, int max_diff, void* scratch, size_t scratch_bytes,
+                              const int32_t* border_roots, void* work, size_t work_bytes, gip_stream stream)
+{
+    GIPK_ARGCHECK(records && border_roots && work && w > 0 && h > 0 && n_tiles > 0 && tile >= 0 && tile < n_tiles);
+    GIPK_ARGCHECK(work_bytes >= gipk_speckle_border_work_bytes(w, n_tiles) && (size_t)2 * w * n_tiles < (1u << 30));
+    if (n_tiles == 1) return GIP_OK;       // nothing crosses a border
+    SpkScratch S;
+    int rc = spk_carve(scratch, scratch_bytes, w, h, 1, &S);
+    if (rc != GIP_OK) return rc;
+    int* par = (int*)gip_align_up((size_t)(uintptr_t)work, 16);
+    int* tot = par + (size_t)2 * w * n_tiles;
+    hipLaunchKernelGGL(k_spk_border_merge, dim3(1), dim3(BRD_TPB), 0, (hipStream_t)stream, (const uint8_t*)records, spk_border_record_bytes(w), n_tiles, tile, w, new_val,
+                       max_diff, S, border_roots, par, tot);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
 int gipk_filter_speckles(int16_t* disp, size_t disp_pitch, int w, int h, int new_val, int max_speckle_size, int max_diff, void* scratch,
                          size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream)
 {
@@ -879,6 +994,14 @@ int gipk_disparity_outputs(const int16_t* disp, size_t disp_pitch, const uint8_t
                            uint8_t* pc_out, int w, int h, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
                            size_t disp_bstride, size_t color_bstride, gip_stream stream)
 {
+    return gipk_disparity_outputs_rows(disp, disp_pitch, color, color_pitch, color_cn, f32_out, pc_out, w, h, 0, Q, cx_l, cx_r, min_disparity, batch, disp_bstride,
+                                       color_bstride, stream);
+}
+
+int gipk_disparity_outputs_rows(const int16_t* disp, size_t disp_pitch, const uint8_t* color, size_t color_pitch, int color_cn, float* f32_out,
+                                uint8_t* pc_out, int w, int h, int y_origin, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
+                                size_t disp_bstride, size_t color_bstride, gip_stream stream)
+{
     GIPK_ARGCHECK(disp && Q && (f32_out || pc_out) && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
     GIPK_ARGCHECK(!pc_out || ((uintptr_t)pc_out & 15) == 0);
     GIPK_ARGCHECK(!color || color_cn == 1 || color_cn == 3);
@@ -889,7 +1012,7 @@ int gipk_disparity_outputs(const int16_t* disp, size_t disp_pitch, const uint8_t
     // the Q of a rectified stereo pair: every entry outside {0, 3, 5, 7, 11, 14, 15} is +0.0
     bool stereo_q = true;
     for (int i : {1, 2, 4, 6, 8, 9, 10, 12, 13}) stereo_q = stereo_q && Q[i] == 0.0 && !std::signbit(Q[i]);
-#define GIP_OUT_ARGS disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q, alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32
+#define GIP_OUT_ARGS disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q, alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32, y_origin
     const dim3 g4(gip_div_up(w, TPB), gip_div_up(h, OUT_ROWS), batch), b4(TPB, 1);
     if (color && color_cn == 1) {
         if (stereo_q) hipLaunchKernelGGL(k_disp_outputs_sq<1>, g4, b4, 0, (hipStream_t)stream, GIP_OUT_ARGS);

@@ -233,3 +233,90 @@ def rowsplit_frame(raw_l, raw_r, maps, params, rank, world_size, speckle_size, s
         colour = rl[y0 - e0:y1 - e0].contiguous()
         f32, cloud = K.disparity_outputs(d, colour, Qt, cx_l, cx_r, params.min_disparity)
     return y0, y1, d, f32, cloud
+
+
+# ------------------------------------------------------------------------------------------------------------------ native form
+class RowSplit:
+    """ctypes holder of gip_rowsplit_* (include/gpuimageproc_hip.h): ONE process owns n_tiles processor handles, every buffer is
+    allocated at open, halo rows travel by hipMemcpyPeerAsync and the components that cross tile borders are merged on the device.
+    The functions above are the one-process-per-GPU (torch.distributed / RCCL) form of the same split."""
+
+    def __init__(self, width, height, calib, params, n_tiles, encoding="mono8", outputs=None, max_speckle_size=0, max_speckle_diff=0.0, devices=None,
+                 halo_mode=0, host_threads=0):
+        import ctypes as C
+        from . import capi
+        from .pipeline import ENCODINGS
+        from .processor import camera_info
+        self._C, self._capi, self._lib = C, capi, capi.lib()
+        self.w, self.h, self.n_tiles = width, height, n_tiles
+        cfg = capi.RowSplitConfig()
+        cfg.width, cfg.height, cfg.encoding = width, height, ENCODINGS[encoding]
+        cfg.outputs = (capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD) if outputs is None else outputs
+        cfg.n_tiles = n_tiles
+        for i in range(16):
+            cfg.devices[i] = devices[i] if devices is not None and i < len(devices) else -1
+        cfg.halo_mode, cfg.host_threads = halo_mode, host_threads
+        self.outputs = cfg.outputs
+        self.channels = 3 if encoding in ("bgr8", "rgb8") else 1
+        li, ri = camera_info(width, height, **calib["left"]), camera_info(width, height, **calib["right"])
+        self.handle = C.c_void_p()
+        rc = self._lib.gip_rowsplit_open(C.byref(li), C.byref(ri), C.byref(params), int(max_speckle_size), float(max_speckle_diff), C.byref(cfg), C.byref(self.handle))
+        if rc != capi.OK:
+            raise capi.GipError(rc, "gip_rowsplit_open")
+        self._keep = []
+
+    def _ck(self, rc):
+        if rc != self._capi.OK:
+            raise self._capi.GipError(rc, self._lib.gip_rowsplit_last_error(self.handle).decode())
+
+    def plan(self, tile):
+        C = self._C
+        v = [C.c_int() for _ in range(5)]
+        self._ck(self._lib.gip_rowsplit_plan(self.handle, tile, *[C.byref(x) for x in v]))
+        return dict(zip(("y0", "y1", "e0", "e1", "device"), [x.value for x in v]))
+
+    def set_inputs(self, tile, left_raw, right_raw):
+        """left_raw / right_raw: contiguous uint8 CUDA tensors of the FULL raw frame on the tile's device (kept alive here)."""
+        assert left_raw.is_cuda and left_raw.is_contiguous() and right_raw.is_contiguous()
+        self._keep = [k for k in self._keep if k[0] != tile] + [(tile, left_raw, right_raw)]
+        self._ck(self._lib.gip_rowsplit_set_inputs_device(self.handle, tile, left_raw.data_ptr(), right_raw.data_ptr()))
+
+    def upload(self, left_raw, right_raw):
+        """host numpy frames -> every tile's device"""
+        l, r = np.ascontiguousarray(left_raw), np.ascontiguousarray(right_raw)
+        assert l.shape[:2] == (self.h, self.w) and r.shape == l.shape and l.dtype == np.uint8
+        self._ck(self._lib.gip_rowsplit_upload(self.handle, l.ctypes.data, r.ctypes.data, 0))
+
+    def run(self):
+        self._ck(self._lib.gip_rowsplit_run(self.handle))
+
+    def wait(self):
+        self._ck(self._lib.gip_rowsplit_wait(self.handle))
+
+    def run_serial(self):
+        t = (self._capi.RowSplitTiming * self.n_tiles)()
+        self._ck(self._lib.gip_rowsplit_run_serial(self.handle, t))
+        return [{n: getattr(x, n) for n, _ in self._capi.RowSplitTiming._fields_} for x in t]
+
+    def last_timing(self, tile):
+        t = self._capi.RowSplitTiming()
+        self._ck(self._lib.gip_rowsplit_last_timing(self.handle, tile, self._C.byref(t)))
+        return {n: getattr(t, n) for n, _ in self._capi.RowSplitTiming._fields_}
+
+    def download(self, want_f32=True, want_cloud=True):
+        d16 = np.empty((self.h, self.w), np.int16)
+        f32 = np.empty((self.h, self.w), np.float32) if want_f32 and (self.outputs & self._capi.TOPIC_DISPARITY) else None
+        pc = np.empty((self.h, self.w, 32), np.uint8) if want_cloud and (self.outputs & self._capi.TOPIC_POINTCLOUD) else None
+        self._ck(self._lib.gip_rowsplit_download(self.handle, d16.ctypes.data, f32.ctypes.data if f32 is not None else None, pc.ctypes.data if pc is not None else None))
+        return d16, f32, pc
+
+    def close(self):
+        if self.handle:
+            self._lib.gip_rowsplit_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
