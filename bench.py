@@ -236,10 +236,106 @@ def e2e_streaming(lraw, rraw, calib, params, device, budget_s=1.5):
             "records": out}
 
 
-def rowsplit_main(args, wl):
-    """BASELINE configs[4]: ONE large frame per step, cut into row tiles over the ranks (strong scaling): every rank rectifies its own
-    rows, swaps halo rows with its neighbours over RCCL point-to-point, matches its tile, takes part in the distributed speckle merge
-    (one all-gather of border rows) and produces float disparity + cloud for its rows.  `value` = frames per second of the whole job."""
+def metric_name(wl):
+    return "stereo pairs/sec + ms/frame disparity, %dx%d ndisp=%d at 1/2/4/8 GPU" % (wl["W"], wl["H"], wl["NDISP"])
+
+
+def rowsplit_native(args, wl):
+    """BASELINE configs[4] through the C-ABI (gip_rowsplit_*): ONE process owns one processor handle per tile (tile t on device t mod the
+    visible devices), every buffer preallocated, halo rows by hipMemcpyPeerAsync, border components merged on the device.  A step is ONE
+    frame.  For every tile count 1, 2, 4 ... up to --tiles: frames/s with two frames in flight (two tile sets taken in turn), the latency of
+    one synchronised frame, and the time every tile needs with its device to itself (gip_rowsplit_run_serial: what a rank on its own GPU
+    spends outside communication).  `value` is the frames/s of the largest tile count.  One frame is checked against the oracle chain."""
+    import torch
+    from ros_gpu_stereo_processor_amd import capi, rowsplit as RS
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    tiles = max(1, args.tiles if args.tiles > 0 else args.gpus)
+    counts = [n for n in (1, 2, 4, 8, 16) if n < tiles] + [tiles]
+    extra_one_device = 4 if (tiles < 4 and not args.no_extra) else 0      # (c) of the round-3 brief: the 4-handle split on whatever devices there are
+    lraw, rraw, calib = make_inputs(2, seed0=100, nseeds=2)
+    params = capi.BMParams(**bm_kwargs())
+    outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
+    dev_frames = {}
+
+    def frames_on(d):
+        if d not in dev_frames:
+            dev_frames[d] = ([torch.from_numpy(x).to("cuda:%d" % d) for x in lraw], [torch.from_numpy(x).to("cuda:%d" % d) for x in rraw])
+        return dev_frames[d]
+
+    def measure(nt, depth=2):
+        devices = [t % ndev for t in range(nt)]
+        groups = [RS.RowSplit(W, H, calib, params, nt, ENCODING, outputs, SPECKLE_SIZE, SPECKLE_DIFF, devices=devices, halo_mode=args.halo_mode, host_threads=args.host_threads)
+                  for _ in range(depth)]
+        for k, g in enumerate(groups):          # group k always works on frame k mod 2: inputs resident in HBM before the timed region
+            for t, d in enumerate(devices):
+                L, R = frames_on(d)
+                g.set_inputs(t, L[k % 2], R[k % 2])
+        for i in range(args.warmup):
+            groups[i % depth].run()
+        for g in groups:
+            g.wait()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            groups[i % depth].run()
+        for g in groups:
+            g.wait()
+        dt = time.perf_counter() - t0
+        lat = []
+        for i in range(15):
+            t1 = time.perf_counter()
+            groups[0].run()
+            groups[0].wait()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        lat.sort()
+        conc = [groups[0].last_timing(t) for t in range(nt)]
+        # every tile's phases with the device to itself, median over several frames (the tile that goes first after a drain pays for the idle device;
+        # run_serial rotates the order)
+        runs = [groups[0].run_serial() for _ in range(9)]
+        serial = [{k: sorted(r[t][k] for r in runs)[len(runs) // 2] for k in runs[0][t]} for t in range(nt)]
+        noncomm = [round(x["front_ms"] + x["match_ms"] + x["post_ms"], 4) for x in serial]
+        d16 = groups[0].download(want_f32=False, want_cloud=False)[0]
+        for g in groups:
+            g.close()
+        rec = {"tiles": nt, "devices": devices, "frames_in_flight": depth, "frames_per_s": round(args.steps / dt, 2), "ms_per_frame": round(1e3 * dt / args.steps, 4),
+               "latency_ms_p50": round(lat[len(lat) // 2], 4), "per_tile_noncomm_ms": noncomm, "per_tile_noncomm_ms_max": max(noncomm),
+               "per_tile_comm_ms_alone": [round(x["halo_ms"] + x["gather_ms"], 4) for x in serial],
+               "per_tile_gpu_ms_concurrent": [round(x["total_ms"], 4) for x in conc],
+               "per_tile_phases_alone_ms": [{k: round(v, 4) for k, v in x.items()} for x in serial]}
+        return rec, d16
+
+    records, verified, exp = [], None, None
+    for nt in counts + ([extra_one_device] if extra_one_device else []):
+        rec, d16 = measure(nt)
+        if nt == extra_one_device and nt not in counts:
+            rec["note"] = "%d handles sharing %d device(s): concurrency without more hardware; the per-tile times alone are what a rank on its own GPU would see" % (nt, ndev)
+        if not args.no_verify:
+            if exp is None:
+                from oracle import oracle as O
+                maps = [O.init_undistort_rectify_map(calib[s_]["K"], calib[s_]["D"], calib[s_]["R"], calib[s_]["P"], W, H) for s_ in ("left", "right")]
+                exp = cpu_chain(O, lraw[0], rraw[0], calib, maps, O.bm_params(**bm_kwargs()))[0]
+            ok = bool(np.array_equal(d16, exp))
+            rec["verified"] = ok
+            verified = ok if verified is None else (verified and ok)
+        records.append(rec)
+    main_rec = [r for r in records if r["tiles"] == tiles][0]
+    out = {"metric": metric_name(wl), "value": main_rec["frames_per_s"], "unit": "stereo pairs/s", "n_gpus": min(tiles, ndev), "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": main_rec["ms_per_frame"], "ms_per_frame": main_rec["ms_per_frame"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+           "data": "synthetic",
+           "config": {"workload": wl["name"] + " -- ROW-TILE SPLIT of one frame over %d tile(s) in ONE process (gip_rowsplit_*): %s, border components merged on the device"
+                                  % (tiles, "every tile rectifies its own halo rows" if args.halo_mode else "halo rows by hipMemcpyPeerAsync"),
+                      "pairs_per_step": 1, "parallelism": "row-tile x%d on %d device(s), halo %d rows" % (tiles, min(tiles, ndev), RS.halo_rows(BLOCK))},
+           "rowsplit": records, "verified": verified}
+    print(json.dumps(out), flush=True)
+    if verified is False:
+        raise SystemExit("row split: the disparity of the timed configuration differs from the oracle")
+
+
+def rowsplit_rccl(args, wl):
+    """BASELINE configs[4], one process per GPU (strong scaling): every rank rectifies its own rows, swaps halo rows with its neighbours over
+    RCCL point-to-point, matches its tile, takes part in the distributed speckle merge (one all-gather of border records, merged on the
+    device) and produces float disparity + cloud for its rows.  `value` = frames per second of the whole job."""
     import torch
     import torch.distributed as dist
     from ros_gpu_stereo_processor_amd import capi, rowsplit as RS
@@ -256,12 +352,11 @@ def rowsplit_main(args, wl):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if rehearse:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lraw, rraw, calib0 = make_inputs(2, seed0=100, nseeds=2)       # the same two frames on every rank (the raw frame is resident everywhere)
     calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
     params = capi.BMParams(**bm_kwargs())
@@ -278,26 +373,54 @@ def rowsplit_main(args, wl):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     dt = gdist.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps({
-            "metric": "stereo pairs/sec + ms/frame disparity, 1242x375 ndisp=128 at 1/2/4/8 GPU", "value": round(args.steps / dt, 2), "unit": "stereo pairs/s", "n_gpus": world,
+            "metric": metric_name(wl), "value": round(args.steps / dt, 2), "unit": "stereo pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "ms_per_frame": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"] + " -- ROW-TILE SPLIT of one frame over %d rank(s): halo exchange (RCCL point-to-point) + distributed speckle merge" % world,
+            "config": {"workload": wl["name"] + " -- ROW-TILE SPLIT of one frame over %d rank(s), one process per GPU: halo exchange (RCCL point-to-point) + all-gather of "
+                                                "border records, merged on the device" % world,
                        "pairs_per_step": 1, "parallelism": "row-tile x%d, halo %d rows" % (world, RS.halo_rows(BLOCK))},
-            "roofline": None, "note": "host-driven per-kernel path (python launches, per-step allocations); compare with the same flags at --gpus 1"}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            "roofline": None, "note": "python-driven per-rank path (torch.distributed); the single-process form (bench.py --rowsplit without torchrun) is the preallocated one"}),
+            flush=True)
+    dist.destroy_process_group()
+
+
+def rowsplit_main(args, wl):
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return rowsplit_rccl(args, wl)
+    return rowsplit_native(args, wl)
+
+
+def rowsplit_secondary(world, timeout_s=150):
+    """The driver only ever runs `bench.py --gpus N`; so that a scaling run measures BASELINE configs[4] at all, rank 0 of an N >= 4 run
+    starts the single-process row split (1, 2 and 4 tiles on devices 0..3) as a CHILD process once the frame-sharded measurement is over
+    (the other ranks' devices are idle by then) and embeds its record.  A child with a time limit: whatever goes wrong there costs the
+    secondary record only, never the main line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "uhd4k", "--rowsplit", "--tiles", "4", "--steps", "60", "--warmup", "6", "--no-extra"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                            "TORCHELASTIC_RUN_ID", "MASTER_PORT")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+        if lines:
+            rec = json.loads(lines[-1])
+            return {"workload": rec["config"]["workload"], "scaling": "strong", "unit": "frames/s", "records": rec.get("rowsplit"), "verified": rec.get("verified"),
+                    "returncode": p.returncode}
+        return {"error": "row-split child printed no record (rc %d): %s" % (p.returncode, (p.stderr or "")[-400:])}
+    except subprocess.TimeoutExpired:
+        return {"error": "row-split child exceeded %d s and was stopped" % timeout_s}
+    except Exception as e:       # noqa: BLE001 -- the secondary record must never take the main line down
+        return {"error": "row-split child failed: %r" % (e,)}
 
 
 def main():
@@ -322,6 +445,12 @@ def main():
                     "(bit-identical; measured slower on MI355X, DESIGN.md 3.3)")
     ap.add_argument("--rowsplit", action="store_true", help="BASELINE configs[4] mode: ONE frame per step cut into row tiles over the ranks (halo exchange + distributed "
                     "speckle over RCCL); use with --workload uhd4k")
+    ap.add_argument("--tiles", type=int, default=0, help="--rowsplit without torchrun: row tiles = processor handles in this one process (default: --gpus); tile t runs on device t mod "
+                    "the visible devices")
+    ap.add_argument("--halo-mode", type=int, default=0, choices=[0, 1], help="--rowsplit: 0 = neighbours exchange rectified halo rows (hipMemcpyPeerAsync), 1 = every tile rectifies its own halo rows")
+    ap.add_argument("--host-threads", type=int, default=0, choices=[0, 1], help="--rowsplit: 0 = one enqueueing host thread per tile, 1 = the calling thread enqueues everything")
+    ap.add_argument("--no-extra", action="store_true", help="--rowsplit: skip the additional 4-handle record on fewer than 4 devices")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of one frame of the timed configuration with the oracle chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-priority", type=int, default=0, help="HIP stream priority of the per-batch streams that carry everything but the matcher (-1 = high)")
     ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
@@ -471,7 +600,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "stereo pairs/sec + ms/frame disparity, 1242x375 ndisp=128 at 1/2/4/8 GPU",
+            "metric": metric_name(wl),
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * args.steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",

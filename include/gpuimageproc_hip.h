@@ -385,19 +385,22 @@ int gipk_speckle_apply(int16_t *disp, size_t disp_pitch, int w, int h, int new_v
                        size_t scratch_bytes, int batch, size_t disp_bstride, gip_stream stream);
 
 /* Device-side merge of the components that cross tile borders (row-tile split; no host round trip):
- *   border_record  after gipk_speckle_label: this tile's record of its first and last row (value, link to the component's canonical border
- *                  pixel, tile-local component size: gipk_speckle_border_record_bytes(w) = 20 bytes per column, rounded up to 256) and
- *                  border_roots[2 w], the tile-local root of every border pixel;
+ *   border_record  after gipk_speckle_label: tile `tile`'s record of its first and last row -- per border pixel the disparity, a union-find
+ *                  parent (the component's canonical border pixel of this tile, as an index into the buffer that holds the records of all
+ *                  tiles in tile order) and the tile-local component size: gipk_speckle_border_record_bytes(w) = 20 bytes per column,
+ *                  rounded up to 256 -- and border_roots[2 w], the tile-local root of every border pixel;
  *   border_merge   `records` = the records of ALL n_tiles tiles, contiguous in tile order, on this device (gathered by peer copies or an
- *                  all-gather); unites the components that touch across the borders and overwrites the sizes of tile `tile`'s own border
- *                  components with the size of the whole component; `work` >= gipk_speckle_border_work_bytes(w, n_tiles).
+ *                  all-gather; MODIFIED in place: they are the union-find forest); unites the components that touch across the borders
+ *                  and overwrites the sizes of tile `tile`'s own border components with the size of the whole component.
  * gipk_speckle_apply then erases exactly what cv::filterSpeckles erases on the full frame. */
 size_t gipk_speckle_border_record_bytes(int w);
-size_t gipk_speckle_border_work_bytes(int w, int n_tiles);
-int gipk_speckle_border_record(const int16_t *disp, size_t disp_pitch, int w, int h, void *scratch, size_t scratch_bytes, void *record,
+int gipk_speckle_border_record(const int16_t *disp, size_t disp_pitch, int w, int h, int tile, void *scratch, size_t scratch_bytes, void *record,
                                int32_t *border_roots, gip_stream stream);
-int gipk_speckle_border_merge(const void *records, int n_tiles, int tile, int w, int h, int new_val, int max_diff, void *scratch,
-                              size_t scratch_bytes, const int32_t *border_roots, void *work, size_t work_bytes, gip_stream stream);
+/* the records of all tiles (tile_records[t]: device pointers; peer memory is read in place when peer access is enabled) copied side by
+ * side into `records` in ONE launch -- the alternative to n_tiles hipMemcpyPeerAsync calls */
+int gipk_speckle_border_gather(const void *const *tile_records, int n_tiles, int w, void *records, gip_stream stream);
+int gipk_speckle_border_merge(void *records, int n_tiles, int tile, int w, int h, int new_val, int max_diff, void *scratch,
+                              size_t scratch_bytes, const int32_t *border_roots, gip_stream stream);
 
 /* reprojectImageTo3D on the float disparity (missing = the image minimum, i.e. `missing_value`) */
 int gipk_reproject_to_3d(const float *disp, size_t disp_pitch, float *xyz, size_t xyz_pitch, int w, int h, const double Q[16],
@@ -487,6 +490,9 @@ typedef struct gip_rowsplit_config {
     int32_t devices[16];     /* HIP device of tile t; a negative entry = t mod gip_device_count() */
     int32_t halo_mode;       /* 0: neighbours exchange rectified halo rows (hipMemcpyPeerAsync); 1: every tile rectifies its halo rows itself */
     int32_t host_threads;    /* 0: one enqueueing host thread per tile when n_tiles > 1; 1: the calling thread enqueues everything */
+    int32_t gather_mode;     /* how a tile collects the other tiles' border records: 0 = auto (one gather kernel when all tiles share its
+                              * device, else one hipMemcpyPeerAsync per tile), 1 = always copies, 2 = always the gather kernel (reads peer
+                              * memory in place; needs peer access between the devices) */
 } gip_rowsplit_config;
 /* per-tile GPU time of the last run (ms, hipEvents on the tile's stream): front = colour + rectify, halo = waiting for and pulling the
  * neighbours' rows, match = prefilter + matcher + L/R check + speckle labelling + border record, gather = waiting for and pulling the

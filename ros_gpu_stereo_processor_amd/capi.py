@@ -97,7 +97,7 @@ class StreamerResult(C.Structure):
 
 class RowSplitConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32), ("n_tiles", C.c_int32),
-                ("devices", C.c_int32 * 16), ("halo_mode", C.c_int32), ("host_threads", C.c_int32)]
+                ("devices", C.c_int32 * 16), ("halo_mode", C.c_int32), ("host_threads", C.c_int32), ("gather_mode", C.c_int32)]
 
 
 class RowSplitTiming(C.Structure):
@@ -208,9 +208,9 @@ PROTOTYPES = {
     "gip_streamer_last_error": (C.c_char_p, [_vp]),
     "gipk_disparity_outputs_rows": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp, _i, _i, _i, C.POINTER(_d), _d, _d, _i, _i, _sz, _sz, _vp]),
     "gipk_speckle_border_record_bytes": (_sz, [_i]),
-    "gipk_speckle_border_work_bytes": (_sz, [_i, _i]),
-    "gipk_speckle_border_record": (_i, [_vp, _sz, _i, _i, _vp, _sz, _vp, _vp, _vp]),
-    "gipk_speckle_border_merge": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "gipk_speckle_border_record": (_i, [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "gipk_speckle_border_gather": (_i, [_vp, _i, _i, _vp, _vp]),
+    "gipk_speckle_border_merge": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "gip_rowsplit_open": (_i, [C.POINTER(CameraInfo), C.POINTER(CameraInfo), C.POINTER(BMParams), _i, _d, C.POINTER(RowSplitConfig), C.POINTER(_vp)]),
     "gip_rowsplit_close": (_i, [_vp]),
     "gip_rowsplit_last_error": (C.c_char_p, [_vp]),

@@ -11,7 +11,8 @@
 //     and merge the components that cross a border ON THE DEVICE (k_spk_border_merge, k_post.hip);
 //   * everything is preallocated at open; the steady state is kernel launches, peer copies and event waits -- no allocation, no host
 //     synchronisation, no host union-find.  One host thread per tile enqueues that tile's work, so the launch overhead of N tiles is paid
-//     in parallel (about 25 enqueue calls per tile and frame).
+//     in parallel (about 25 enqueue calls per tile and frame).  (Replaying each tile's launches from hipGraphs was measured: 3-7 % SLOWER
+//     per tile on ROCm 7.2 -- the graph's kernel nodes do not follow each other any closer than stream launches do -- and dropped.)
 // Data layout: the rectified rows of both eyes INTERLEAVED in one buffer (row i = [left row i | right row i], pitch 2 * rp): the halo
 // rows of both eyes are then ONE contiguous block per neighbour, i.e. one hipMemcpyPeerAsync per boundary and direction.
 #include <atomic>
@@ -47,10 +48,9 @@ struct Tile {
     int16_t* d_ext = nullptr;                      // (e1 - e0) x w
     void* spk_scratch = nullptr;
     size_t spk_scratch_bytes = 0;
-    uint8_t* records = nullptr;                    // n_tiles border records (this tile's own at index t)
+    uint8_t* pub_record = nullptr;                 // this tile's border record as the other tiles pull it
+    uint8_t* records = nullptr;                    // the records of all n_tiles tiles: this tile's working copy (the union-find forest of its merge)
     int32_t* border_roots = nullptr;               // 2 w
-    void* merge_work = nullptr;
-    size_t merge_work_bytes = 0;
     float* f32 = nullptr;                          // own rows
     uint8_t* pc = nullptr;
     hipEvent_t ev_rect = nullptr, ev_rec = nullptr, ev_done = nullptr;   // cross-tile dependencies
@@ -58,6 +58,7 @@ struct Tile {
     hipEvent_t sev = nullptr;                      // gip_rowsplit_run_serial: start of the phase being timed
     gip_rowsplit_timing serial_tm{};
     bool serial_valid = false;
+    bool gather_kernel = false;                    // collect the border records with one kernel (else one copy per tile)
     bool ran = false;
 };
 
@@ -144,7 +145,7 @@ int tile_begin(gip_rowsplit_s* rs, Tile& T)
     return GIP_OK;
 }
 
-int tile_front(gip_rowsplit_s* rs, Tile& T)
+int front_body(gip_rowsplit_s* rs, Tile& T)
 {
     const int w = rs->cfg.width, hh = rs->cfg.height, enc = rs->cfg.encoding;
     const size_t npx = (size_t)w * hh;
@@ -188,6 +189,14 @@ int tile_front(gip_rowsplit_s* rs, Tile& T)
         else
             RS_HIP(rs, hipMemcpyAsync(T.rect_color, color_l + (size_t)T.y0 * w * 3, (size_t)n * w * 3, hipMemcpyDeviceToDevice, T.st));
     }
+    return GIP_OK;
+}
+
+int tile_front(gip_rowsplit_s* rs, Tile& T)
+{
+    if (!T.raw[0] || !T.raw[1]) return rs_fail(rs, GIP_ERR_EMPTY_SLOT, "rowsplit: no input frame on tile " + std::to_string(T.t));
+    int rc = front_body(rs, T);
+    if (rc != GIP_OK) return rc;
     RS_HIP(rs, hipEventRecord(T.ev_rect, T.st));
     RS_HIP(rs, hipEventRecord(T.tev[1], T.st));
     return GIP_OK;
@@ -213,7 +222,7 @@ int tile_halo(gip_rowsplit_s* rs, Tile& T)
     return GIP_OK;
 }
 
-int tile_match(gip_rowsplit_s* rs, Tile& T)
+int match_body(gip_rowsplit_s* rs, Tile& T)
 {
     const int w = rs->cfg.width, he = T.e1 - T.e0, hown = T.y1 - T.y0;
     const size_t pitch = 2 * rs->rp;
@@ -228,39 +237,60 @@ int tile_match(gip_rowsplit_s* rs, Tile& T)
         const int new_val = (rs->bp.min_disparity - 1) * 16;
         RS_STEP(rs, gipk_speckle_label(d_own, (size_t)w * 2, w, hown, new_val, rs->spk_diff16, T.spk_scratch, T.spk_scratch_bytes, 1, 0, T.st), "speckle label");
         if (rs->tiles.size() > 1) {
-            RS_STEP(rs, gipk_speckle_border_record(d_own, (size_t)w * 2, w, hown, T.spk_scratch, T.spk_scratch_bytes, T.records + (size_t)T.t * rs->rec_bytes, T.border_roots, T.st),
+            RS_STEP(rs, gipk_speckle_border_record(d_own, (size_t)w * 2, w, hown, T.t, T.spk_scratch, T.spk_scratch_bytes, T.pub_record, T.border_roots, T.st),
                     "border record");
-            RS_HIP(rs, hipEventRecord(T.ev_rec, T.st));
         }
     }
+    return GIP_OK;
+}
+
+int tile_match(gip_rowsplit_s* rs, Tile& T)
+{
+    int rc = match_body(rs, T);
+    if (rc != GIP_OK) return rc;
+    if (rs->spk_size > 0 && rs->tiles.size() > 1) RS_HIP(rs, hipEventRecord(T.ev_rec, T.st));
     RS_HIP(rs, hipEventRecord(T.tev[3], T.st));
     return GIP_OK;
 }
 
 int tile_gather(gip_rowsplit_s* rs, Tile& T, bool wait_host)
 {
-    if (rs->spk_size > 0 && rs->tiles.size() > 1) {
+    if (rs->spk_size > 0 && rs->tiles.size() > 1 && T.gather_kernel) {
+        const void* src[16];
         for (Tile& O : rs->tiles) {
+            src[O.t] = O.pub_record;
             if (O.t == T.t) continue;
             if (wait_host)
                 while (rs->rec_gen[O.t].load(std::memory_order_acquire) < rs->frame) std::this_thread::yield();
             RS_HIP(rs, hipStreamWaitEvent(T.st, O.ev_rec, 0));
-            RS_HIP(rs, hipMemcpyPeerAsync(T.records + (size_t)O.t * rs->rec_bytes, T.device, O.records + (size_t)O.t * rs->rec_bytes, O.device, (size_t)20 * rs->cfg.width, T.st));
+        }
+        RS_STEP(rs, gipk_speckle_border_gather(src, (int)rs->tiles.size(), rs->cfg.width, T.records, T.st), "border gather");
+    } else if (rs->spk_size > 0 && rs->tiles.size() > 1) {
+        for (Tile& O : rs->tiles) {
+            uint8_t* dst = T.records + (size_t)O.t * rs->rec_bytes;
+            if (O.t == T.t) {
+                RS_HIP(rs, hipMemcpyAsync(dst, T.pub_record, (size_t)20 * rs->cfg.width, hipMemcpyDeviceToDevice, T.st));
+                continue;
+            }
+            if (wait_host)
+                while (rs->rec_gen[O.t].load(std::memory_order_acquire) < rs->frame) std::this_thread::yield();
+            RS_HIP(rs, hipStreamWaitEvent(T.st, O.ev_rec, 0));
+            RS_HIP(rs, hipMemcpyPeerAsync(dst, T.device, O.pub_record, O.device, (size_t)20 * rs->cfg.width, T.st));
         }
     }
     RS_HIP(rs, hipEventRecord(T.tev[4], T.st));
     return GIP_OK;
 }
 
-int tile_post(gip_rowsplit_s* rs, Tile& T)
+int post_body(gip_rowsplit_s* rs, Tile& T)
 {
     const int w = rs->cfg.width, hown = T.y1 - T.y0;
     int16_t* d_own = T.d_ext + (size_t)(T.y0 - T.e0) * w;
     if (rs->spk_size > 0) {
         const int new_val = (rs->bp.min_disparity - 1) * 16;
         if (rs->tiles.size() > 1)
-            RS_STEP(rs, gipk_speckle_border_merge(T.records, (int)rs->tiles.size(), T.t, w, hown, new_val, rs->spk_diff16, T.spk_scratch, T.spk_scratch_bytes, T.border_roots,
-                                                  T.merge_work, T.merge_work_bytes, T.st), "border merge");
+            RS_STEP(rs, gipk_speckle_border_merge(T.records, (int)rs->tiles.size(), T.t, w, hown, new_val, rs->spk_diff16, T.spk_scratch, T.spk_scratch_bytes, T.border_roots, T.st),
+                    "border merge");
         RS_STEP(rs, gipk_speckle_apply(d_own, (size_t)w * 2, w, hown, new_val, rs->spk_size, T.spk_scratch, T.spk_scratch_bytes, 1, 0, T.st), "speckle apply");
     }
     if (T.f32 || T.pc) {
@@ -274,6 +304,13 @@ int tile_post(gip_rowsplit_s* rs, Tile& T)
         RS_STEP(rs, gipk_disparity_outputs_rows(d_own, (size_t)w * 2, col, cpitch, cn, T.f32, T.pc, w, hown, T.y0, T.v.Q, T.v.cx_l, T.v.cx_r, rs->bp.min_disparity, 1, 0, 0, T.st),
                 "disparity outputs");
     }
+    return GIP_OK;
+}
+
+int tile_post(gip_rowsplit_s* rs, Tile& T)
+{
+    int rc = post_body(rs, T);
+    if (rc != GIP_OK) return rc;
     RS_HIP(rs, hipEventRecord(T.tev[5], T.st));
     RS_HIP(rs, hipEventRecord(T.ev_done, T.st));
     T.ran = true;
@@ -326,7 +363,7 @@ void free_tile(Tile& T)
 {
     (void)hipSetDevice(T.device);
     if (T.st) (void)hipStreamSynchronize(T.st);
-    void* bufs[] = {T.own_raw[0], T.own_raw[1], T.mono[0], T.mono[1], T.color, T.rect, T.rect_color, T.bm_scratch, T.d_ext, T.spk_scratch, T.records, T.border_roots, T.merge_work,
+    void* bufs[] = {T.own_raw[0], T.own_raw[1], T.mono[0], T.mono[1], T.color, T.rect, T.rect_color, T.bm_scratch, T.d_ext, T.spk_scratch, T.records, T.pub_record, T.border_roots,
                     T.f32, T.pc};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -374,7 +411,7 @@ int gip_rowsplit_open(const gip_camera_info* left, const gip_camera_info* right,
     if (!left || !right || !params || !cfg || !out) return GIP_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->encoding < 0 || cfg->encoding > 6 || cfg->n_tiles < 1 || cfg->n_tiles > 16 || max_speckle_size < 0 ||
-        max_speckle_diff < 0.0 || (cfg->halo_mode != 0 && cfg->halo_mode != 1))
+        max_speckle_diff < 0.0 || (cfg->halo_mode != 0 && cfg->halo_mode != 1) || cfg->gather_mode < 0 || cfg->gather_mode > 2)
         return GIP_ERR_INVALID_ARG;
     const int ndev = gip_device_count();
     if (ndev <= 0) return GIP_ERR_NO_DEVICE;
@@ -431,9 +468,8 @@ int gip_rowsplit_open(const gip_camera_info* left, const gip_camera_info* right,
             T.spk_scratch_bytes = gipk_speckle_scratch_bytes(w, hown, 1);
             ok = ok && hipMalloc(&T.spk_scratch, T.spk_scratch_bytes) == hipSuccess;
             if (N > 1) {
-                T.merge_work_bytes = gipk_speckle_border_work_bytes(w, N);
-                ok = ok && hipMalloc((void**)&T.records, rs->rec_bytes * N) == hipSuccess && hipMalloc((void**)&T.border_roots, (size_t)2 * w * 4) == hipSuccess &&
-                     hipMalloc(&T.merge_work, T.merge_work_bytes) == hipSuccess;
+                ok = ok && hipMalloc((void**)&T.records, rs->rec_bytes * N) == hipSuccess && hipMalloc((void**)&T.pub_record, rs->rec_bytes) == hipSuccess &&
+                     hipMalloc((void**)&T.border_roots, (size_t)2 * w * 4) == hipSuccess;
             }
         }
         if (want_f32 || want_pc) ok = ok && hipMalloc((void**)&T.f32, (size_t)hown * w * 4) == hipSuccess;
@@ -457,6 +493,11 @@ int gip_rowsplit_open(const gip_camera_info* left, const gip_camera_info* right,
                     if (e != hipSuccess) (void)hipGetLastError();      // already enabled, or refused: both fine
                 }
             }
+    for (Tile& A : rs->tiles) {
+        bool same = true;
+        for (Tile& B : rs->tiles) same = same && A.device == B.device;
+        A.gather_kernel = cfg->gather_mode == 2 || (cfg->gather_mode == 0 && same);
+    }
     rs->rect_gen = new (std::nothrow) std::atomic<uint64_t>[N];
     rs->rec_gen = new (std::nothrow) std::atomic<uint64_t>[N];
     if (!rs->rect_gen || !rs->rec_gen) return fail(GIP_ERR_HIP);
@@ -610,18 +651,22 @@ int gip_rowsplit_run_serial(gip_rowsplit rs, gip_rowsplit_timing* timing)
         tm[T.t].*field = ms;
         return GIP_OK;
     };
+    // the tile that goes first after a drain finds the device idle (clocks down, caches cold): rotate the order from call to call so that
+    // the effect does not always land on tile 0 (callers take the median over several calls)
+    const int N = (int)rs->tiles.size(), first = (int)(rs->frame % (uint64_t)N);
+    auto at = [&](int i) -> Tile& { return rs->tiles[(first + i) % N]; };
     for (Tile& T : rs->tiles)
         if ((rc = tile_begin(rs, T)) != GIP_OK) return rc;
-    for (Tile& T : rs->tiles)
-        if ((rc = timed(T, tile_front, 1, &gip_rowsplit_timing::front_ms)) != GIP_OK) return rc;
-    for (Tile& T : rs->tiles)
-        if ((rc = timed(T, tile_halo, 2, &gip_rowsplit_timing::halo_ms)) != GIP_OK) return rc;
-    for (Tile& T : rs->tiles)
-        if ((rc = timed(T, tile_match, 3, &gip_rowsplit_timing::match_ms)) != GIP_OK) return rc;
-    for (Tile& T : rs->tiles)
-        if ((rc = timed(T, [](gip_rowsplit_s* r, Tile& X) { return tile_gather(r, X, false); }, 4, &gip_rowsplit_timing::gather_ms)) != GIP_OK) return rc;
-    for (Tile& T : rs->tiles)
-        if ((rc = timed(T, tile_post, 5, &gip_rowsplit_timing::post_ms)) != GIP_OK) return rc;
+    for (int i = 0; i < N; i++)
+        if ((rc = timed(at(i), tile_front, 1, &gip_rowsplit_timing::front_ms)) != GIP_OK) return rc;
+    for (int i = 0; i < N; i++)
+        if ((rc = timed(at(i), tile_halo, 2, &gip_rowsplit_timing::halo_ms)) != GIP_OK) return rc;
+    for (int i = 0; i < N; i++)
+        if ((rc = timed(at(i), tile_match, 3, &gip_rowsplit_timing::match_ms)) != GIP_OK) return rc;
+    for (int i = 0; i < N; i++)
+        if ((rc = timed(at(i), [](gip_rowsplit_s* r, Tile& X) { return tile_gather(r, X, false); }, 4, &gip_rowsplit_timing::gather_ms)) != GIP_OK) return rc;
+    for (int i = 0; i < N; i++)
+        if ((rc = timed(at(i), tile_post, 5, &gip_rowsplit_timing::post_ms)) != GIP_OK) return rc;
     rs->frames_done = true;
     for (Tile& T : rs->tiles) {
         gip_rowsplit_timing& x = tm[T.t];

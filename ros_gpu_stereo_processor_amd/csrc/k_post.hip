@@ -233,6 +233,18 @@ __device__ __forceinline__ void uf_union(int* nd, int a, int b)
     } while (!done);
 }
 
+// True in the first lane of every run of consecutive lanes that hold the same key (lanes without `on` break a run).  The union-find
+// kernels below use it to drop redundant unions: neighbouring joins of a row mostly connect the same two large components, and
+// thousands of atomics on one address serialise (54 us for the border link, 39 us for the border union before this).  Runs, not
+// distinct keys: a loop that serves one distinct key at a time serialises rows with many small components (k_spk_cross: 22 -> 53 us).
+__device__ __forceinline__ bool first_of_key_run(bool on, u64 key)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const u64 prev = ((u64)(u32)__shfl_up((int)(key >> 32), 1) << 32) | (u64)(u32)__shfl_up((int)key, 1);
+    const int prev_on = __shfl_up(on ? 1 : 0, 1);
+    return on && !(lane > 0 && prev_on && prev == key);
+}
+
 // the same on an LDS array (workgroup scope)
 __device__ __forceinline__ int lds_find(int* nd, int i)
 {
@@ -477,17 +489,27 @@ __global__ void __launch_bounds__(SPK_TPB) k_spk_strip(SpkScratch S, int w, int 
     }
 }
 
-__global__ void __launch_bounds__(64) k_spk_cross(SpkScratch S, int w, int h, int nstrips)
+constexpr int SPK_CROSS_TPB = 256;     // four waves per boundary row: a row of a 4096-wide map has hundreds of joins, each a chain of dependent accesses
+__global__ void __launch_bounds__(SPK_CROSS_TPB) k_spk_cross(SpkScratch S, int w, int h, int nstrips)
 {
     const int y = blockIdx.x;                       // joins between rows y and y+1
     if (((y + 1) % SPK_STRIP) != 0 && !S.global_strip[blockIdx.z * (size_t)nstrips + y / SPK_STRIP]) return;
     const size_t ibase = blockIdx.z * (size_t)w * h;
     const size_t rb = ibase + (size_t)y * w;
     const int n = S.njoin[blockIdx.z * (size_t)h + y];
-    for (int k = threadIdx.x; k < n; k += 64) {
-        const u32 item = S.joinlist[rb + k];
-        const int x = (int)(item >> 16);
-        uf_union(S.parent + ibase, y * w + (int)(item & 0xFFFFu), (y + 1) * w + (int)S.ord16[rb + w + x]);
+    int* nd = S.parent + ibase;
+    for (int k0 = 0; k0 < n; k0 += SPK_CROSS_TPB) {
+        const int k = k0 + (int)threadIdx.x;
+        int a = 0, b = 0;
+        if (k < n) {
+            const u32 item = S.joinlist[rb + k];
+            const int x = (int)(item >> 16);
+            // the strip-local roots of the two runs (or, concurrently relinked, an ancestor: all a union needs); neighbouring joins mostly
+            // connect the same two large components: one union per run of equal pairs
+            a = __hip_atomic_load(&nd[y * w + (int)(item & 0xFFFFu)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = __hip_atomic_load(&nd[(y + 1) * w + (int)S.ord16[rb + w + x]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (first_of_key_run(k < n, ((u64)(u32)a << 32) | (u64)(u32)b)) uf_union(nd, a, b);
     }
 }
 
@@ -502,7 +524,10 @@ __global__ void __launch_bounds__(64) k_spk_sizes(SpkScratch S, int w, int h)
         const int sz = S.csize[ibase + i];
         if (sz == 0) continue;                          // not a strip-local root
         int root = nd[i];
-        if (root == i) continue;                        // still a root: its size stays where it is
+        if (root == i) {                                // still a root: its size stays where it is
+            S.joinlist[ibase + i] = 0x7FFFFFFFu;        // (row-tile split: k_spk_border_link takes the minimum border pixel of the component here;
+            continue;                                   //  the join lists are dead once k_spk_cross has run)
+        }
         int q = nd[root];
         while (q != root) { root = q; q = nd[root]; }   // k_spk_cross is complete: plain loads are coherent
         nd[i] = root;                                   // compression: local roots now point straight at the global root
@@ -567,84 +592,109 @@ __global__ void __launch_bounds__(256) k_spk_set_sizes(SpkScratch S, const int* 
 
 // ---- row-tile split (BASELINE configs[4]): components that cross tile borders, merged ON THE DEVICE --------------------------------
 // A frame cut into N row tiles is labelled tile by tile (gipk_speckle_label on every tile's own rows).  What the tiles must agree on is
-// the size of the components that continue across a border.  Each tile publishes a BORDER RECORD of its first and last row -- per pixel
-// p in [0, 2w) (p < w: first row, else last row): the disparity value, `link` = the smallest border-pixel index of the same component
-// in this tile (-1: invalid pixel; link[p] == p marks the component's canonical border pixel) and the component's tile-local size --
-// 20 bytes per image column.  The records of all tiles are brought together (hipMemcpyPeerAsync / an all-gather), and every tile runs
-// k_spk_border_merge on them: a union-find over the 2wN border pixels (pixels of one component of one tile are pre-linked through
-// `link`; pixels facing each other across a border are united when cv::filterSpeckles' rule connects them), component totals at the
-// roots, and the sizes of the tile's OWN border components overwritten with the total of the whole component -- k_spk_apply then
-// erases exactly what the filter on the full frame erases.  No host round trip, no host union-find.
-constexpr int BRD_TPB = 1024;
+// the size of the components that continue across a border.  Each tile publishes a BORDER RECORD of its first and last row: for the 2w
+// border pixels p (p < w: first row, else last row)
+//     val  int16[2w] @ byte 0     the disparity
+//     par  int32[2w] @ byte 4w    union-find parent, as an int32 index into the buffer that holds the records of ALL tiles one after the
+//                                 other (record stride S ints): the node of pixel p of tile t is  t*S + w + p.  Initially the node of the
+//                                 component's CANONICAL border pixel (the smallest p of that component in this tile); an invalid pixel
+//                                 points at itself
+//     size int32[2w] @ byte 12w   tile-local size of the component at its canonical pixel, 0 elsewhere  (node + 2w)
+// 20 bytes per image column.  Once the records of all tiles sit side by side on a device (hipMemcpyPeerAsync / an all-gather) they ARE a
+// union-find forest over the 2wN border pixels with every tile's components pre-linked: k_spk_border_union unites the pixels that face
+// each other across a border when cv::filterSpeckles' rule connects them, k_spk_border_accum adds the sizes of the absorbed components
+// to their roots, k_spk_border_patch overwrites the sizes of the tile's OWN border components with the total -- k_spk_apply then erases
+// exactly what the filter on the full frame erases.  No host round trip.  All kernels are grids of one thread per border pixel: a
+// first version with ONE workgroup per step (dependent global accesses in a loop) took 78 + 93 us per tile and frame.
+constexpr int BRD_TPB = 256;
 __host__ __device__ inline size_t spk_border_record_bytes(int w) { return ((size_t)20 * w + 255) / 256 * 256; }
-__device__ __forceinline__ const int16_t* brd_val(const uint8_t* rec) { return (const int16_t*)rec; }
-__device__ __forceinline__ const int* brd_link(const uint8_t* rec, int w) { return (const int*)(rec + (size_t)4 * w); }
-__device__ __forceinline__ const int* brd_size(const uint8_t* rec, int w) { return (const int*)(rec + (size_t)12 * w); }
 
-// one workgroup; S = the labelled tile (after k_spk_sizes); roots[2w] (out) = tile-local root node of every border pixel, -1 = invalid
-__global__ void __launch_bounds__(BRD_TPB) k_spk_border_record(const int16_t* __restrict__ disp, size_t dpitch, SpkScratch S, int w, int h, uint8_t* __restrict__ rec,
-                                                                int* __restrict__ roots)
+// canon[root] (the join-list slot of the root node; k_spk_sizes has set it to INT_MAX) <- smallest border pixel of the component
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_link(SpkScratch S, int w, int h, int* __restrict__ roots)
 {
-    int* canon = (int*)S.joinlist;          // one slot per node; the join lists are dead once k_spk_cross has run
-    const int n2 = 2 * w;
-    for (int p = threadIdx.x; p < n2; p += BRD_TPB) {
+    const int p = blockIdx.x * BRD_TPB + threadIdx.x;
+    int root = -1;
+    if (p < 2 * w) {
         const int row = p < w ? 0 : h - 1, x = p < w ? p : p - w;
         const unsigned ord = S.ord16[(size_t)row * w + x];
-        int root = -1;
         if (ord != 0xFFFFu) {
             const int r1 = S.parent[(size_t)row * w + ord];
             root = S.parent[r1];            // k_spk_sizes left the global root in every strip-local root
-            canon[root] = 0x7FFFFFFF;
         }
         roots[p] = root;
     }
-    __syncthreads();
-    for (int p = threadIdx.x; p < n2; p += BRD_TPB) {
-        const int root = roots[p];
-        if (root >= 0) __hip_atomic_fetch_min(&canon[root], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    int16_t* val = (int16_t*)rec;
-    int* link = (int*)(rec + (size_t)4 * w);
-    int* size = (int*)(rec + (size_t)12 * w);
-    for (int p = threadIdx.x; p < n2; p += BRD_TPB) {
-        const int row = p < w ? 0 : h - 1, x = p < w ? p : p - w;
-        const int root = roots[p];
-        val[p] = disp[(size_t)row * dpitch + x];
-        link[p] = root >= 0 ? __hip_atomic_load(&canon[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        size[p] = root >= 0 ? S.csize[root] : 0;
-    }
+    // the first lane of a run of equal roots holds the smallest p of the run
+    if (first_of_key_run(root >= 0, (u64)(u32)root)) __hip_atomic_fetch_min((int*)S.joinlist + root, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one workgroup; recs = the records of all n_tiles tiles (rec_stride bytes apart), `me` = the tile whose sizes are patched (S, roots);
-// par / tot = 2 w n_tiles ints of scratch each
-__global__ void __launch_bounds__(BRD_TPB) k_spk_border_merge(const uint8_t* __restrict__ recs, size_t rec_stride, int n_tiles, int me, int w, int new_val, int max_diff,
-                                                               SpkScratch S, const int* __restrict__ roots, int* par, int* tot)
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_record(const int16_t* __restrict__ disp, size_t dpitch, SpkScratch S, int w, int h, int tile, uint8_t* __restrict__ rec,
+                                                                const int* __restrict__ roots)
 {
-    const int n2 = 2 * w, N = n_tiles * n2;
-#pragma unroll 4
-    for (int g = threadIdx.x; g < N; g += BRD_TPB) {
-        const int t = g / n2, p = g - t * n2;
-        const int lk = brd_link(recs + t * rec_stride, w)[p];
-        par[g] = lk >= 0 ? t * n2 + lk : g;
-        tot[g] = 0;
+    const int p = blockIdx.x * BRD_TPB + threadIdx.x;
+    if (p >= 2 * w) return;
+    const int row = p < w ? 0 : h - 1, x = p < w ? p : p - w;
+    const int base = tile * (int)(spk_border_record_bytes(w) / 4) + w;      // node of this tile's pixel 0
+    const int root = roots[p];
+    int canon = p, size = 0;
+    if (root >= 0) {
+        canon = ((const int*)S.joinlist)[root];
+        if (canon == p) size = S.csize[root];
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (n_tiles - 1) * w; i += BRD_TPB) {
+    ((int16_t*)rec)[p] = disp[(size_t)row * dpitch + x];
+    ((int*)(rec + (size_t)4 * w))[p] = base + canon;
+    ((int*)(rec + (size_t)12 * w))[p] = size;
+}
+
+// nodes = int32 view of the gathered records; S = record stride in ints
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_union(uint8_t* recs, int S, int n_tiles, int w, int new_val, int max_diff)
+{
+    const int i = blockIdx.x * BRD_TPB + threadIdx.x;
+    bool on = false;
+    int a = 0, c = 0;
+    if (i < (n_tiles - 1) * w) {
         const int b = i / w, x = i - b * w;
-        const int vb = brd_val(recs + b * rec_stride)[w + x], vt = brd_val(recs + (b + 1) * rec_stride)[x];
-        if (spk_conn(vb, vt, new_val, max_diff)) uf_union(par, b * n2 + w + x, (b + 1) * n2 + x);
+        const int vb = ((const int16_t*)(recs + (size_t)b * S * 4))[w + x], vt = ((const int16_t*)(recs + (size_t)(b + 1) * S * 4))[x];
+        if (spk_conn(vb, vt, new_val, max_diff)) {
+            // the two pixels' parents: the canonical pixels of their components when this kernel starts (possibly relinked by now: still
+            // an ancestor, which is all a union needs) -- equal for every pair that joins the same two components
+            on = true;
+            a = __hip_atomic_load((int*)recs + b * S + w + (w + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = __hip_atomic_load((int*)recs + (b + 1) * S + w + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int g = threadIdx.x; g < N; g += BRD_TPB) {
-        const int t = g / n2, p = g - t * n2;
-        if (brd_link(recs + t * rec_stride, w)[p] == p) atomicAdd(&tot[uf_find(par, g)], brd_size(recs + t * rec_stride, w)[p]);
-    }
-    __syncthreads();
-    const int* mylink = brd_link(recs + me * rec_stride, w);
-    for (int p = threadIdx.x; p < n2; p += BRD_TPB)
-        if (mylink[p] == p) S.csize[roots[p]] = __hip_atomic_load(&tot[uf_find(par, me * n2 + p)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first_of_key_run(on, ((u64)(u32)a << 32) | (u64)(u32)c)) uf_union((int*)recs, a, c);
+}
+
+// the records of all tiles -> this tile's working copy, ONE launch: src[t] may be peer memory (hipDeviceEnablePeerAccess)
+struct BorderSrc { const uint8_t* p[16]; };
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_gather(BorderSrc src, uint8_t* __restrict__ dst, int S4 /* record stride in 16-byte units */, int n_used4, int n_tiles)
+{
+    const int i = blockIdx.x * BRD_TPB + threadIdx.x;
+    if (i >= n_used4 * n_tiles) return;
+    const int t = i / n_used4, k = i - t * n_used4;
+    ((uint4*)dst)[(size_t)t * S4 + k] = ((const uint4*)src.p[t])[k];
+}
+
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_accum(uint8_t* recs, int S, int n_tiles, int w)
+{
+    const int i = blockIdx.x * BRD_TPB + threadIdx.x, n2 = 2 * w;
+    if (i >= n_tiles * n2) return;
+    const int t = i / n2, p = i - t * n2, g = t * S + w + p;
+    int* nd = (int*)recs;
+    const int sz = nd[g + n2];
+    if (sz == 0) return;                       // not a canonical pixel
+    const int R = uf_find(nd, g);
+    if (R != g) atomicAdd(&nd[R + n2], sz);    // an absorbed component: nobody adds to ITS size, so the plain read above is safe
+}
+
+__global__ void __launch_bounds__(BRD_TPB) k_spk_border_patch(uint8_t* recs, int S, int me, int w, SpkScratch Sc, const int* __restrict__ roots)
+{
+    const int p = blockIdx.x * BRD_TPB + threadIdx.x, n2 = 2 * w;
+    if (p >= n2) return;
+    const int root = roots[p];
+    if (root < 0 || ((const int*)Sc.joinlist)[root] != p) return;      // invalid, or not the component's canonical pixel
+    int* nd = (int*)recs;
+    Sc.csize[root] = nd[uf_find(nd, me * S + w + p) + n2];
 }
 
 // ---------------------------------------------------------------------------------------- reprojection / cloud
@@ -826,6 +876,7 @@ static int finalize_launch(int16_t* disp, size_t disp_pitch, const CT* cost, siz
     if (w <= 2 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<2, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
     else if (w <= 5 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<5, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
     else if (w <= 8 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<8, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    else if (w <= 16 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<16, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
     else hipLaunchKernelGGL(k_bm_finalize<CT>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
 #undef GIP_FINALIZE_ARGS
     GIP_LAUNCH_CHECK();
@@ -886,7 +937,7 @@ int gipk_speckle_label(const int16_t* disp, size_t disp_pitch, int w, int h, int
     if (pairs_ok) hipLaunchKernelGGL(k_spk_scan2, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     else hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     hipLaunchKernelGGL(k_spk_strip, dim3(nstrips, 1, batch), dim3(SPK_TPB), (size_t)SPK_CAP * 8, st, S, w, h, nstrips);
-    if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(64), 0, st, S, w, h, nstrips);
+    if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(SPK_CROSS_TPB), 0, st, S, w, h, nstrips);
     hipLaunchKernelGGL(k_spk_sizes, dim3(h, 1, batch), dim3(64), 0, st, S, w, h);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
@@ -929,33 +980,50 @@ int gipk_speckle_set_sizes(void* scratch, size_t scratch_bytes, int w, int h, in
 }
 
 size_t gipk_speckle_border_record_bytes(int w) { return w > 0 ? spk_border_record_bytes(w) : 0; }
-size_t gipk_speckle_border_work_bytes(int w, int n_tiles) { return (w > 0 && n_tiles > 0) ? (size_t)16 * w * n_tiles + 256 : 0; }
 
-int gipk_speckle_border_record(const int16_t* disp, size_t disp_pitch, int w, int h, void* scratch, size_t scratch_bytes, void* record, int32_t* border_roots,
+int gipk_speckle_border_record(const int16_t* disp, size_t disp_pitch, int w, int h, int tile, void* scratch, size_t scratch_bytes, void* record, int32_t* border_roots,
                                gip_stream stream)
 {
-    GIPK_ARGCHECK(disp && record && border_roots && w > 0 && h > 0 && disp_pitch % 2 == 0 && ((uintptr_t)record & 3) == 0);
+    GIPK_ARGCHECK(disp && record && border_roots && w > 0 && h > 0 && tile >= 0 && disp_pitch % 2 == 0 && ((uintptr_t)record & 3) == 0);
+    GIPK_ARGCHECK((size_t)(tile + 1) * spk_border_record_bytes(w) < ((size_t)1 << 31));      // node indices are int32
     SpkScratch S;
     int rc = spk_carve(scratch, scratch_bytes, w, h, 1, &S);
     if (rc != GIP_OK) return rc;
-    hipLaunchKernelGGL(k_spk_border_record, dim3(1), dim3(BRD_TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, S, w, h, (uint8_t*)record, border_roots);
+    const dim3 grid(gip_div_up(2 * w, BRD_TPB));
+    hipLaunchKernelGGL(k_spk_border_link, grid, dim3(BRD_TPB), 0, (hipStream_t)stream, S, w, h, border_roots);
+    hipLaunchKernelGGL(k_spk_border_record, grid, dim3(BRD_TPB), 0, (hipStream_t)stream, disp, disp_pitch / 2, S, w, h, tile, (uint8_t*)record, border_roots);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
 
-int gipk_speckle_border_merge(const void* records, int n_tiles, int tile, int w, int h, int new_val, int max_diff, void* scratch, size_t scratch_bytes,
-                              const int32_t* border_roots, void* work, size_t work_bytes, gip_stream stream)
+int gipk_speckle_border_gather(const void* const* tile_records, int n_tiles, int w, void* records, gip_stream stream)
 {
-    GIPK_ARGCHECK(records && border_roots && work && w > 0 && h > 0 && n_tiles > 0 && tile >= 0 && tile < n_tiles);
-    GIPK_ARGCHECK(work_bytes >= gipk_speckle_border_work_bytes(w, n_tiles) && (size_t)2 * w * n_tiles < (1u << 30));
+    GIPK_ARGCHECK(tile_records && records && n_tiles > 0 && n_tiles <= 16 && w > 0 && ((uintptr_t)records & 15) == 0);
+    BorderSrc src{};
+    for (int t = 0; t < n_tiles; t++) {
+        GIPK_ARGCHECK(tile_records[t] && ((uintptr_t)tile_records[t] & 15) == 0);
+        src.p[t] = (const uint8_t*)tile_records[t];
+    }
+    const int used4 = (int)(((size_t)20 * w + 15) / 16), stride4 = (int)(spk_border_record_bytes(w) / 16);
+    hipLaunchKernelGGL(k_spk_border_gather, dim3(gip_div_up(used4 * n_tiles, BRD_TPB)), dim3(BRD_TPB), 0, (hipStream_t)stream, src, (uint8_t*)records, stride4, used4, n_tiles);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
+int gipk_speckle_border_merge(void* records, int n_tiles, int tile, int w, int h, int new_val, int max_diff, void* scratch, size_t scratch_bytes,
+                              const int32_t* border_roots, gip_stream stream)
+{
+    GIPK_ARGCHECK(records && border_roots && w > 0 && h > 0 && n_tiles > 0 && tile >= 0 && tile < n_tiles && ((uintptr_t)records & 3) == 0);
+    GIPK_ARGCHECK((size_t)n_tiles * spk_border_record_bytes(w) < ((size_t)1 << 31));
     if (n_tiles == 1) return GIP_OK;       // nothing crosses a border
     SpkScratch S;
     int rc = spk_carve(scratch, scratch_bytes, w, h, 1, &S);
     if (rc != GIP_OK) return rc;
-    int* par = (int*)gip_align_up((size_t)(uintptr_t)work, 16);
-    int* tot = par + (size_t)2 * w * n_tiles;
-    hipLaunchKernelGGL(k_spk_border_merge, dim3(1), dim3(BRD_TPB), 0, (hipStream_t)stream, (const uint8_t*)records, spk_border_record_bytes(w), n_tiles, tile, w, new_val,
-                       max_diff, S, border_roots, par, tot);
+    const int stride = (int)(spk_border_record_bytes(w) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_spk_border_union, dim3(gip_div_up((n_tiles - 1) * w, BRD_TPB)), dim3(BRD_TPB), 0, st, (uint8_t*)records, stride, n_tiles, w, new_val, max_diff);
+    hipLaunchKernelGGL(k_spk_border_accum, dim3(gip_div_up(n_tiles * 2 * w, BRD_TPB)), dim3(BRD_TPB), 0, st, (uint8_t*)records, stride, n_tiles, w);
+    hipLaunchKernelGGL(k_spk_border_patch, dim3(gip_div_up(2 * w, BRD_TPB)), dim3(BRD_TPB), 0, st, (uint8_t*)records, stride, tile, w, S, border_roots);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }

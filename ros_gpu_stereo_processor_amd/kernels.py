@@ -197,6 +197,24 @@ class SpeckleLabels:
         z = torch.as_tensor(sizes, dtype=torch.int32, device=self.disp.device).contiguous()
         _ck(self.L.gipk_speckle_set_sizes(self.scratch.data_ptr(), self.nbytes, self.W, self.H, 1, r.data_ptr(), z.data_ptr(), r.numel(), _stream()))
 
+    def border_record(self, tile):
+        """Tile `tile`'s border record (uint8 tensor, gipk_speckle_border_record_bytes(W) bytes): first and last row as value / union-find
+        parent (canonical border pixel of the component) / tile-local component size -- what the ranks all-gather (rowsplit.distributed_speckle)."""
+        n = self.L.gipk_speckle_border_record_bytes(self.W)
+        rec = torch.zeros(n, dtype=torch.uint8, device=self.disp.device)
+        self._roots = torch.empty(2 * self.W, dtype=torch.int32, device=self.disp.device)
+        _ck(self.L.gipk_speckle_border_record(self.disp.data_ptr(), self.W * 2, self.W, self.H, int(tile), self.scratch.data_ptr(), self.nbytes, rec.data_ptr(),
+                                              self._roots.data_ptr(), _stream()))
+        return rec
+
+    def border_merge(self, records, n_tiles, tile, max_diff):
+        """records: the border records of ALL tiles, concatenated in tile order, on this device (a private copy: modified in place).  Unites
+        the components that touch across the tile borders (on the device) and overwrites the sizes of this tile's border components with the
+        size of the whole component."""
+        assert records.is_cuda and records.is_contiguous() and records.numel() == n_tiles * self.L.gipk_speckle_border_record_bytes(self.W)
+        _ck(self.L.gipk_speckle_border_merge(records.data_ptr(), int(n_tiles), int(tile), self.W, self.H, self.new_val, int(max_diff), self.scratch.data_ptr(), self.nbytes,
+                                             self._roots.data_ptr(), _stream()))
+
     def apply(self, max_speckle_size):
         _ck(self.L.gipk_speckle_apply(self.disp.data_ptr(), self.W * 2, self.W, self.H, self.new_val, int(max_speckle_size), self.scratch.data_ptr(), self.nbytes, 1,
                                       self.H * self.W * 2, _stream()))
@@ -241,9 +259,10 @@ def disparity_to_pointcloud2(disp, bgr, Q, cx_l, cx_r, min_disparity):
     return out if disp.dim() == 3 else out[0]
 
 
-def disparity_outputs(disp, colour, Q, cx_l, cx_r, min_disparity, want_f32=True, want_cloud=True):
+def disparity_outputs(disp, colour, Q, cx_l, cx_r, min_disparity, want_f32=True, want_cloud=True, y_origin=0):
     """Fused tail of the chain on ONE (H,W) int16 disparity: float disparity d/16 - (cx_l - cx_r) and the 32-byte PointCloud2 records.
-    colour: (H,W) mono (replicated, = GRAY2BGR) or (H,W,3) BGR rectified image, or None."""
+    colour: (H,W) mono (replicated, = GRAY2BGR) or (H,W,3) BGR rectified image, or None.  y_origin: the tile holds rows
+    [y_origin, y_origin + H) of a larger frame (row-tile split)."""
     L = capi.lib()
     assert disp.dim() == 2 and disp.is_contiguous()
     H, W = disp.shape
@@ -252,9 +271,9 @@ def disparity_outputs(disp, colour, Q, cx_l, cx_r, min_disparity, want_f32=True,
     cn = 0 if colour is None else (3 if colour.dim() == 3 else 1)
     if colour is not None:
         assert colour.is_contiguous() and colour.shape[0] == H and colour.shape[1] == W
-    _ck(L.gipk_disparity_outputs(disp.data_ptr(), W * 2, colour.data_ptr() if colour is not None else None, W * cn, cn if cn else 3, f32.data_ptr() if want_f32 else None,
-                                 pc.data_ptr() if want_cloud else None, W, H, _q(np.asarray(Q, np.float64)), float(cx_l), float(cx_r), int(min_disparity), 1, H * W * 2,
-                                 H * W * cn, _stream()))
+    _ck(L.gipk_disparity_outputs_rows(disp.data_ptr(), W * 2, colour.data_ptr() if colour is not None else None, W * cn, cn if cn else 3, f32.data_ptr() if want_f32 else None,
+                                      pc.data_ptr() if want_cloud else None, W, H, int(y_origin), _q(np.asarray(Q, np.float64)), float(cx_l), float(cx_r), int(min_disparity), 1,
+                                      H * W * 2, H * W * cn, _stream()))
     return f32, pc
 
 

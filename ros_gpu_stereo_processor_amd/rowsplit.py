@@ -6,12 +6,15 @@ NORMALIZED_RESPONSE it is block radius + prefilter radius + 1).  Each rank recti
 with its neighbours (point-to-point over xGMI: RCCL send/recv, 2 x halo x W bytes per boundary and image), runs the matcher
 on its extended tile and keeps the rows whose windows never touched the tile's artificial top/bottom border.  The L/R
 consistency check is row-local and needs nothing extra.  The speckle filter is global (a component may cross tile borders):
-every rank labels the components of its own rows, the ranks all-gather their first and last rows (value, component root, component
-size: 10 bytes per pixel), every rank merges the components that touch across a border with a small host union-find, patches the
-sizes of its own border components to the size of the whole component and erases what is small (distributed_speckle below; the
-single exchange of SURVEY.md section 8(e)).  Cloud and float disparity are produced per tile.
+every rank labels the components of its own rows, the ranks all-gather a 20-byte-per-column record of their first and last rows, every
+rank merges the components that touch across a border ON THE DEVICE, patches the sizes of its own border components to the size of the
+whole component and erases what is small (distributed_speckle below; the single exchange of SURVEY.md section 8(e)).  Cloud and float
+disparity are produced per tile.
 
-The same functions drive the single-GPU parity test (ranks simulated one after the other) and the gloo test of the exchange.
+Two forms of the same split: the functions below are the one-process-per-GPU form (torch.distributed: RCCL point-to-point for the halo
+rows, one all-gather for the border records); class RowSplit at the end holds the native form (gip_rowsplit_* of the C-ABI: one process
+owns N handles, everything preallocated, hipMemcpyPeerAsync).  The same functions drive the single-GPU parity test (ranks simulated one
+after the other) and the gloo test of the exchange.
 """
 import numpy as np
 import torch
@@ -121,85 +124,44 @@ def split_stereobm_simulated(rect_l, rect_r, params, world_size, block_size, pre
 
 
 # ------------------------------------------------------------------------------------------------------------------ speckle
-def _connected(a, b, new_val, max_diff):
-    return (a != new_val) & (b != new_val) & (np.abs(a.astype(np.int64) - b.astype(np.int64)) <= max_diff)
-
-
-def merge_border_components(rows, new_val, max_diff):
-    """rows[t] = (top_vals, top_roots, top_sizes, bot_vals, bot_roots, bot_sizes) of rank t (numpy, one entry per image column; roots
-    are rank-local ids, -1 for invalid pixels).  Components that touch across the border between rank t and t+1 (4-connectivity: same
-    column, both valid, |difference| <= max_diff -- cv::filterSpeckles' rule) are united; returns per rank {root: size of the whole
-    component} for every root that appears in one of its border rows."""
-    parent, size = {}, {}
-
-    def find(n):
-        while parent[n] != n:
-            parent[n] = parent[parent[n]]
-            n = parent[n]
-        return n
-    for t, (tv, tr, ts, bv, br, bs) in enumerate(rows):
-        for roots, sizes in ((tr, ts), (br, bs)):
-            valid = roots >= 0
-            for r, z in zip(*np.unique(np.stack([roots[valid], sizes[valid]]), axis=1)) if valid.any() else ():
-                parent.setdefault((t, int(r)), (t, int(r)))
-                size[(t, int(r))] = int(z)
-    for t in range(len(rows) - 1):
-        bv, br = rows[t][3], rows[t][4]
-        tv, tr = rows[t + 1][0], rows[t + 1][1]
-        con = _connected(bv, tv, new_val, max_diff) & (br >= 0) & (tr >= 0)
-        if not con.any():
-            continue
-        for a, b in zip(*np.unique(np.stack([br[con], tr[con]]), axis=1)):
-            ra, rb = find((t, int(a))), find((t + 1, int(b)))
-            if ra != rb:
-                parent[rb] = ra
-    total = {}
-    for n in parent:
-        total[find(n)] = total.get(find(n), 0) + size[n]
-    out = [dict() for _ in rows]
-    for (t, r) in parent:
-        out[t][r] = total[find((t, r))]
-    return out
+def border_record_layout(w):
+    """Byte layout of a tile's border record (k_spk_border_record, csrc/k_post.hip): for the 2 w border pixels p (p < w: the tile's first
+    row, else its last row)  value int16[2w] @0,  par int32[2w] @4w (union-find parent: node of the component's canonical border pixel of
+    this tile; the node of pixel p of tile t is  t * nbytes / 4 + w + p  -- an int32 index into the concatenated records; an invalid pixel
+    points at itself),  size int32[2w] @12w (tile-local component size at the canonical pixel, 0 elsewhere); padded to a multiple of 256 bytes."""
+    return dict(val=(0, 2 * w), par=(4 * w, 2 * w), size=(12 * w, 2 * w), nbytes=(20 * w + 255) // 256 * 256)
 
 
 def distributed_speckle(tile, rank, world_size, new_val, max_size, max_diff, group=None, labeler=None):
     """cv::filterSpeckles on a frame that is split into row tiles: `tile` holds this rank's rows (int16, modified in place and
-    returned).  labeler(tile, new_val, max_diff) -> object with row_labels(row) -> (roots, sizes), set_sizes(roots, sizes),
-    apply(max_size); the default is the HIP implementation (kernels.SpeckleLabels)."""
+    returned).  Every rank labels its own rows, publishes its border record, the ranks all-gather the records (the single exchange of
+    SURVEY.md section 8(e): 20 bytes per column and rank), and every rank merges the components that cross a border and patches the sizes
+    of its own border components -- ON THE DEVICE for the default labeler (kernels.SpeckleLabels: gipk_speckle_border_record / _merge),
+    no host round trip.  labeler(tile, new_val, max_diff) -> object with border_record() -> uint8 tensor, border_merge(records, n_tiles,
+    tile, max_diff), apply(max_size); border_record takes the rank."""
     if labeler is None:
         from .kernels import SpeckleLabels as labeler
     lab = labeler(tile, new_val, max_diff)
     if world_size > 1:
-        h = tile.shape[0]
-        tr, ts = lab.row_labels(0)
-        br, bs = lab.row_labels(h - 1)
-        mine = torch.stack([tile[0].to(torch.int32), tr.to(torch.int32), ts.to(torch.int32), tile[h - 1].to(torch.int32), br.to(torch.int32), bs.to(torch.int32)])
-        everyone = [torch.empty_like(mine) for _ in range(world_size)]
-        dist.all_gather(everyone, mine, group=group)
-        rows = [tuple(e.cpu().numpy()) for e in everyone]
-        patch = merge_border_components(rows, new_val, max_diff)[rank]
-        if patch:
-            lab.set_sizes(list(patch.keys()), list(patch.values()))
+        rec = lab.border_record(rank)
+        everyone = [torch.empty_like(rec) for _ in range(world_size)]
+        dist.all_gather(everyone, rec, group=group)
+        lab.border_merge(torch.cat(everyone), world_size, rank, max_diff)
     return lab.apply(max_size)
 
 
 def split_speckle_simulated(disp, world_size, new_val, max_size, max_diff):
-    """Single-process rehearsal of distributed_speckle on the HIP labeler: every 'rank' labels its own rows, the border rows are
-    merged exactly as the ranks would after the all-gather, sizes patched, tiles erased and stitched."""
+    """Single-process rehearsal of distributed_speckle on the HIP labeler: every 'rank' labels its own rows, the border records are
+    concatenated as the all-gather would, every tile merges on the device, patches its sizes, erases; tiles stitched."""
     from .kernels import SpeckleLabels
     h = disp.shape[0]
     ranges = plan(h, world_size)
     tiles = [disp[a:b].contiguous().clone() for a, b in ranges]
     labs = [SpeckleLabels(t, new_val, max_diff) for t in tiles]
-    rows = []
-    for t, lab in zip(tiles, labs):
-        tr, ts = lab.row_labels(0)
-        br, bs = lab.row_labels(t.shape[0] - 1)
-        rows.append(tuple(x.cpu().numpy().astype(np.int32) for x in (t[0], tr, ts, t[-1], br, bs)))
-    patches = merge_border_components(rows, new_val, max_diff)
-    for lab, patch in zip(labs, patches):
-        if patch:
-            lab.set_sizes(list(patch.keys()), list(patch.values()))
+    records = torch.cat([lab.border_record(t) for t, lab in enumerate(labs)])
+    for t, lab in enumerate(labs):
+        if world_size > 1:
+            lab.border_merge(records.clone(), world_size, t, max_diff)      # every rank merges on its own copy
         lab.apply(max_size)
     return torch.cat(tiles, 0)
 
@@ -226,12 +188,10 @@ def rowsplit_frame(raw_l, raw_r, maps, params, rank, world_size, speckle_size, s
         d = distributed_speckle(d, rank, world_size, (params.min_disparity - 1) * 16, speckle_size, speckle_diff16, group)
     f32 = cloud = None
     if want_cloud and Q is not None:
-        # the reprojection depends on the row index: shift the row terms of Q by the tile origin (q.. + q.. * y0)
-        Qt = np.array(Q, np.float64).reshape(4, 4).copy()
-        Qt[:, 3] += Qt[:, 1] * y0
+        # the reprojection depends on the row index of the FULL frame: the kernel adds the tile origin to its row number
         e0, _ = extended_range(h, y0, y1, halo)
         colour = rl[y0 - e0:y1 - e0].contiguous()
-        f32, cloud = K.disparity_outputs(d, colour, Qt, cx_l, cx_r, params.min_disparity)
+        f32, cloud = K.disparity_outputs(d, colour, np.array(Q, np.float64).reshape(4, 4), cx_l, cx_r, params.min_disparity, y_origin=y0)
     return y0, y1, d, f32, cloud
 
 
@@ -242,7 +202,7 @@ class RowSplit:
     The functions above are the one-process-per-GPU (torch.distributed / RCCL) form of the same split."""
 
     def __init__(self, width, height, calib, params, n_tiles, encoding="mono8", outputs=None, max_speckle_size=0, max_speckle_diff=0.0, devices=None,
-                 halo_mode=0, host_threads=0):
+                 halo_mode=0, host_threads=0, gather_mode=0):
         import ctypes as C
         from . import capi
         from .pipeline import ENCODINGS
@@ -255,7 +215,7 @@ class RowSplit:
         cfg.n_tiles = n_tiles
         for i in range(16):
             cfg.devices[i] = devices[i] if devices is not None and i < len(devices) else -1
-        cfg.halo_mode, cfg.host_threads = halo_mode, host_threads
+        cfg.halo_mode, cfg.host_threads, cfg.gather_mode = halo_mode, host_threads, gather_mode
         self.outputs = cfg.outputs
         self.channels = 3 if encoding in ("bgr8", "rgb8") else 1
         li, ri = camera_info(width, height, **calib["left"]), camera_info(width, height, **calib["right"])

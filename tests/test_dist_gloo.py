@@ -100,8 +100,10 @@ def test_rowsplit_halo_exchange_world3():
 
 
 class _CpuLabels:
-    """Host stand-in for kernels.SpeckleLabels (the merge logic of rowsplit.distributed_speckle is device-agnostic): components of
-    ONE tile by flood fill with cv::filterSpeckles' connectivity rule; roots are arbitrary tile-local ids."""
+    """Host stand-in for kernels.SpeckleLabels so that the EXCHANGE of rowsplit.distributed_speckle (one all-gather of border records in
+    the layout of k_spk_border_record) runs over gloo without a GPU: components of ONE tile by flood fill with cv::filterSpeckles'
+    connectivity rule (roots are arbitrary tile-local ids), border record and border merge restated in numpy.  Test infrastructure only:
+    the product labeler does both steps on the device (tests/test_gpu_rowsplit.py, test_gpu_pipeline.py check it against the oracle)."""
 
     def __init__(self, tile, new_val, max_diff):
         self.tile, self.new_val = tile, new_val
@@ -127,13 +129,64 @@ class _CpuLabels:
                             stack.append((ny, nx))
                 self.sizes[rid] = n
 
-    def row_labels(self, row):
-        r = self.lab[row]
-        return torch.from_numpy(r.astype(np.int32)), torch.from_numpy(np.array([self.sizes.get(int(v), 0) for v in r], np.int32))
+    def _rows(self):
+        h = self.tile.shape[0]
+        return (0, h - 1)
 
-    def set_sizes(self, roots, sizes):
-        for r, z in zip(roots, sizes):
-            self.sizes[int(r)] = int(z)
+    def border_record(self, tile):
+        """the record layout of k_spk_border_record (rowsplit.border_record_layout), filled on the host"""
+        from ros_gpu_stereo_processor_amd import rowsplit as RS
+        w = self.tile.shape[1]
+        lay = RS.border_record_layout(w)
+        S = lay["nbytes"] // 4
+        lab = np.concatenate([self.lab[r] for r in self._rows()])
+        val = np.concatenate([self.tile.numpy()[r] for r in self._rows()]).astype(np.int16)
+        par = (tile * S + w + np.arange(2 * w)).astype(np.int32)       # invalid pixels point at themselves
+        size = np.zeros(2 * w, np.int32)
+        first = {}
+        for p, rid in enumerate(lab):
+            if rid >= 0:
+                if int(rid) not in first:
+                    first[int(rid)] = p
+                    size[p] = self.sizes[int(rid)]
+                par[p] = tile * S + w + first[int(rid)]
+        self._border_lab, self._canon = lab, first
+        rec = np.zeros(lay["nbytes"], np.uint8)
+        rec[lay["val"][0]:lay["val"][0] + 4 * w] = val.view(np.uint8)
+        rec[lay["par"][0]:lay["par"][0] + 8 * w] = par.view(np.uint8)
+        rec[lay["size"][0]:lay["size"][0] + 8 * w] = size.view(np.uint8)
+        return torch.from_numpy(rec)
+
+    def border_merge(self, records, n_tiles, tile, max_diff):
+        """what k_spk_border_union / _accum / _patch do, on the host: the concatenated records are the union-find forest"""
+        from ros_gpu_stereo_processor_amd import rowsplit as RS
+        w = self.tile.shape[1]
+        lay = RS.border_record_layout(w)
+        S, n2 = lay["nbytes"] // 4, 2 * w
+        nd = records.numpy().copy().view(np.int32)                       # int32 view: node g = t * S + w + p, its size at g + 2w
+        val = records.numpy().reshape(n_tiles, lay["nbytes"])[:, :4 * w].copy().view(np.int16).astype(np.int64)
+
+        def find(i):
+            while nd[i] != i:
+                nd[i] = nd[nd[i]]
+                i = nd[i]
+            return int(i)
+        for b in range(n_tiles - 1):
+            for x in range(w):
+                vb, vt = val[b][w + x], val[b + 1][x]
+                if vb != self.new_val and vt != self.new_val and abs(vb - vt) <= max_diff:
+                    ra, rb = find(b * S + w + w + x), find((b + 1) * S + w + x)
+                    if ra != rb:
+                        nd[max(ra, rb)] = min(ra, rb)
+        for t in range(n_tiles):
+            for p in range(n2):
+                g = t * S + w + p
+                if nd[g + n2] != 0:
+                    r = find(g)
+                    if r != g:
+                        nd[r + n2] += nd[g + n2]
+        for rid, p in self._canon.items():
+            self.sizes[rid] = int(nd[find(tile * S + w + p) + n2])
 
     def apply(self, max_size):
         a = self.tile.numpy()
@@ -174,7 +227,7 @@ def _speckle_worker(rank, world, port, q):
 
 
 def test_distributed_speckle_world3(oracle):
-    """Row-tile split, speckle filter: every rank labels its own rows, one all-gather of the border rows, host merge of the components
+    """Row-tile split, speckle filter: every rank labels its own rows, one all-gather of the border records, merge of the components
     that touch across a border, sizes patched, then the local erase -- stitched result == cv::filterSpeckles on the whole frame."""
     world, port = 3, _free_port()
     ctx = mp.get_context("spawn")

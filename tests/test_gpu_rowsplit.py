@@ -50,15 +50,16 @@ def _check(got, exp):
     assert np.array_equal(pc[..., 12:], epc[..., 12:])
 
 
-@pytest.mark.parametrize("n_tiles,halo_mode,host_threads", [(1, 0, 0), (2, 0, 0), (3, 0, 1), (3, 1, 0), (5, 0, 0), (5, 1, 1)])
-def test_rowsplit_native_matches_oracle(gpu, oracle, n_tiles, halo_mode, host_threads):
+@pytest.mark.parametrize("n_tiles,halo_mode,host_threads,gather_mode", [(1, 0, 0, 0), (2, 0, 0, 0), (3, 0, 1, 1), (3, 1, 0, 0), (5, 0, 0, 1), (5, 1, 1, 2)])
+def test_rowsplit_native_matches_oracle(gpu, oracle, n_tiles, halo_mode, host_threads, gather_mode):
     """Odd height, block 11, speckle filter on: 1..5 tiles, both halo modes (exchange / every tile rectifies its own halo rows), threaded
-    and single-threaded enqueue; three frames back to back through the same object (the cross-frame event fences)."""
+    and single-threaded enqueue, border records collected by one kernel or by one copy per tile; three frames back to back through the
+    same object (the cross-frame event fences)."""
     from ros_gpu_stereo_processor_amd import capi, rowsplit as RS
     w, h, nd, block = 640, 301, 48, 11
     calib = synth.scaled_calibration(w, h)
     kw = _kw(nd, block)
-    rs = RS.RowSplit(w, h, calib, capi.BMParams(**kw), n_tiles, "mono8", None, 120, 2.0, halo_mode=halo_mode, host_threads=host_threads)
+    rs = RS.RowSplit(w, h, calib, capi.BMParams(**kw), n_tiles, "mono8", None, 120, 2.0, halo_mode=halo_mode, host_threads=host_threads, gather_mode=gather_mode)
     plans = [rs.plan(t) for t in range(n_tiles)]
     assert plans[0]["y0"] == 0 and plans[-1]["y1"] == h and all(a["y1"] == b["y0"] for a, b in zip(plans, plans[1:]))
     assert all(p["e0"] % 2 == 0 and p["e0"] <= p["y0"] and p["e1"] >= p["y1"] for p in plans)
