@@ -451,6 +451,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, choices=[0, 1], help="--rowsplit: 0 = one enqueueing host thread per tile, 1 = the calling thread enqueues everything")
     ap.add_argument("--no-extra", action="store_true", help="--rowsplit: skip the additional 4-handle record on fewer than 4 devices")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of one frame of the timed configuration with the oracle chain")
+    ap.add_argument("--no-secondary", action="store_true", help="only the metric's own workload: no hd1080 / refdefault / utest_timing records, no row-split child at N >= 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-priority", type=int, default=0, help="HIP stream priority of the per-batch streams that carry everything but the matcher (-1 = high)")
     ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
@@ -469,16 +470,8 @@ def main():
     W, H, NDISP, BLOCK, ENCODING = wl["W"], wl["H"], wl["NDISP"], wl["BLOCK"], wl["ENCODING"]
     if args.rowsplit:
         return rowsplit_main(args, wl)
-    if args.batch <= 0:
-        args.batch = wl["batch"]
-    if args.depth <= 0:
-        args.depth = wl["depth"]
-    shared_matcher = wl["shared"] if args.matcher_stream == "auto" else args.matcher_stream == "shared"
-
     import torch
     import torch.distributed as dist
-    from ros_gpu_stereo_processor_amd import capi
-    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -498,24 +491,67 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctx = dict(torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, dev=dev)
+    out = chain_workload(args, args.workload, wl, ctx, args.steps, args.warmup, args.batch, args.depth, probes=True)
+    if rank == 0:
+        # the other headline shapes on the same record (N = 1 only): north_star's second size (BASELINE configs[2]), the reference constructor's
+        # own matcher shape, and the shape of the reference's only timing harness -- each with value, roofline and CPU baseline
+        if world == 1 and args.workload == "kitti" and not args.no_secondary and args.ndisp == 0 and args.block == 0:
+            sec = []
+            for name, steps in (("hd1080", 60), ("refdefault", 100)):
+                wl2 = dict(WORKLOADS[name])
+                set_workload(wl2)
+                sec.append(chain_workload(args, name, wl2, ctx, steps, 6, 0, 0, probes=False))
+            sec.append(utest_timing_record(args, ctx))
+            set_workload(wl)
+            out["secondary"] = sec
+            out["verified"] = bool(out.get("verified")) and all(r.get("verified") is not False for r in sec)
+        # ... and BASELINE configs[4] (row-tile split of one 4096x2160 frame) when there are devices to split over
+        if world >= 4 and not rehearse and not args.no_secondary and os.environ.get("GIP_BENCH_NO_ROWSPLIT") != "1":
+            out["rowsplit"] = None       # filled in below, once the other ranks have left their devices
+    # the frame-sharded job ends here for everybody; the other ranks release their GPUs before rank 0 starts the row-split child
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if "rowsplit" in out:
+            time.sleep(2.0)          # let the other ranks exit
+            out["rowsplit"] = rowsplit_secondary(world)
+        print(json.dumps(out), flush=True)
+        if out.get("verified") is False:
+            raise SystemExit("bench.py: an output of the timed configuration differs from the oracle chain")
 
+
+def set_workload(wl):
+    global W, H, NDISP, BLOCK, ENCODING
+    W, H, NDISP, BLOCK, ENCODING = wl["W"], wl["H"], wl["NDISP"], wl["BLOCK"], wl["ENCODING"]
+
+
+def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
+    """One chain workload (the globals W, H, ... are set to it): returns the record on rank 0 (None elsewhere).  probes: the main line's
+    extras (single-pair latency, end-to-end streaming); the CPU baseline and the oracle check of the timed configuration are always there."""
+    torch, dist, world, rank, local_rank, dev = ctx["torch"], ctx["dist"], ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"]
+    from ros_gpu_stereo_processor_amd import capi
     from ros_gpu_stereo_processor_amd import dist as gdist
-    B = args.batch
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+    B = batch if batch > 0 else wl["batch"]
+    depth = depth if depth > 0 else wl["depth"]
+    shared_matcher = wl["shared"] if args.matcher_stream == "auto" else args.matcher_stream == "shared"
     # BASELINE configs[3]: a synthetic bag of BAG_FRAMES stereo pairs (30 s at 30 fps), frame g -> rank g mod N (dist.frame_shard), no
     # data-path collective.  A step is one batch of B pairs PER RANK, so step i of rank r holds the bag frames
     # ((i * B + j) * N + r) mod BAG_FRAMES, j = 0..B-1: N ranks together walk the bag front to back, each on its own shard
     # ("weak" scaling: the per-GPU work of a step does not depend on N).  The bag cycles through NSCENES distinct synthetic scenes.
-    BAG_FRAMES, NSCENES = 900, 8
+    BAG_FRAMES, NSCENES = 900, (8 if probes else 4)
     lscene, rscene, calib0 = make_inputs(NSCENES, seed0=100, nseeds=NSCENES)
-    lraw, rraw = lscene, rscene     # host copies (latency / e2e probes)
+    lraw, rraw = lscene, rscene     # host copies (latency / e2e probes, oracle check)
     # Calibration + rectification tables: rank 0 owns the CameraInfo, builds the fixed-point tables on its host (double
     # precision) and broadcasts both once over RCCL (xGMI); the other ranks run on exactly those tables.  Frames are
     # independent units (frame i -> rank i mod N, dist.frame_shard), so no collective follows on the data path.
     calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
     params = capi.BMParams(**bm_kwargs())
     outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
-    pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True, fused_front_end=args.fused_front_end, batches_in_flight=max(1, args.depth))
-             for _ in range(max(1, args.depth))]
+    pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True, fused_front_end=args.fused_front_end, batches_in_flight=max(1, depth))
+             for _ in range(max(1, depth))]
     streams = [torch.cuda.Stream(device=dev, priority=args.chain_priority) for _ in pipes]
     matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if (len(pipes) > 1 and shared_matcher) else None
     # "two": two matcher streams taken in turn, so that the ragged end of one matcher launch overlaps the start of the next
@@ -530,12 +566,15 @@ def main():
     scenes_l, scenes_r = torch.from_numpy(lscene).to(dev), torch.from_numpy(rscene).to(dev)
     j = torch.arange(B, device=dev)
 
+    def scene_of(i, jj):
+        return (((i * B + jj) * world + rank) % BAG_FRAMES) % NSCENES
+
     def step_inputs(i):
-        frames = ((i * B + j) * world + rank) % BAG_FRAMES
-        idx = frames % NSCENES
+        idx = (((i * B + j) * world + rank) % BAG_FRAMES) % NSCENES
         return scenes_l.index_select(0, idx).contiguous(), scenes_r.index_select(0, idx).contiguous()
-    nsteps_total = args.warmup + args.steps
-    inputs = [step_inputs(i) for i in range(min(nsteps_total, 32))]    # 32 distinct batches (3.8 GB at the default shape), then they repeat
+    nsteps_total = warmup + steps
+    ninputs = min(nsteps_total, 32)                                # 32 distinct batches (3.8 GB at the default shape), then they repeat
+    inputs = [step_inputs(i) for i in range(ninputs)]
     left, right = inputs[0]
 
     def run_step(i):
@@ -562,7 +601,7 @@ def main():
         a_bm, _, a_n = pipes[0].timing_read()
         bm_alone_ms = a_bm / max(a_n, 1)
         pipes[0].batches_in_flight = len(pipes)
-    for i in range(args.warmup):
+    for i in range(warmup):
         run_step(i)
     torch.cuda.synchronize()
     for p in pipes:
@@ -570,8 +609,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(args.warmup + i)
+    for i in range(steps):
+        run_step(warmup + i)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -579,8 +618,9 @@ def main():
 
     dt_max = gdist.max_over_ranks(dt, dev)
 
+    out = None
     if rank == 0:
-        pairs = world * B * args.steps
+        pairs = world * B * steps
         value = pairs / dt_max
         bm_ms = bm_ms_sum / max(runs, 1)
         if len(pipes) == 1:
@@ -590,24 +630,49 @@ def main():
         # "SAD-only kernel on rectified input"); one launch processes B pairs.
         algo_bytes = 4.0 * W * H * B
         achieved = algo_bytes / (bm_ms * 1e-3) / 1e9 if bm_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("batch") == B and tj.get("workload") == "1242x375_nd128_b9" and args.workload == "kitti":
+                if tj.get("batch") == B and tj.get("workload") == "1242x375_nd128_b9" and key == "kitti":
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "static: profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, not measured in this run)"
             except Exception:
                 traffic = None
+        # the timed configuration checked against the oracle (outside the timing): frame 0 of the LAST step every pipeline ran, the whole chain
+        verified = None
+        if not args.no_verify:
+            from oracle import oracle as O
+            omaps = [O.init_undistort_rectify_map(calib[s_]["K"], calib[s_]["D"], calib[s_]["R"], calib[s_]["P"], W, H) for s_ in ("left", "right")]
+            po = O.bm_params(**bm_kwargs())
+            verified, cache = True, {}
+            for k in range(len(pipes)):
+                last = [i for i in range(warmup + steps) if i % len(pipes) == k]
+                if not last:
+                    continue
+                sc = scene_of(last[-1] % ninputs, 0)
+                if sc not in cache:
+                    cache[sc] = cpu_chain(O, lraw[sc], rraw[sc], calib, omaps, po)
+                e16, epc = cache[sc]
+                g16 = pipes[k].disparity[0].cpu().numpy()
+                gpc = pipes[k].pointcloud[0].cpu().numpy()
+                gx, ex = gpc[..., :12].copy().view(np.float32), epc[..., :12].copy().view(np.float32)
+                ok = np.array_equal(g16, e16) and np.array_equal(np.isnan(gx), np.isnan(ex)) and np.array_equal(gpc[..., 12:], epc[..., 12:])
+                fin = ~np.isnan(ex)
+                ok = ok and bool(np.allclose(gx[fin], ex[fin], rtol=2.4e-7, atol=0))      # float xyz: <= 1 ulp, as in tests/test_gpu_pipeline.py
+                ok = ok and np.array_equal(pipes[k].disparity_f32[0].cpu().numpy(), O.disparity_to_f32(e16, calib["left"]["P"][2], calib["right"]["P"][2]))
+                verified = verified and bool(ok)
         out = {
             "metric": metric_name(wl),
-            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt_max / args.steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * args.steps), 5),
+            "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt_max / steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
                        "parallelism": "frame-sharded x%d: frame g of a %d-frame bag -> rank g mod %d" % (world, BAG_FRAMES, world)},
+            "verified": verified,
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_ms": round(bm_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(bm_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes, "chain_gpu_ms_per_step": round(total_ms_sum / max(runs, 1), 4),
                          # kernel_ms is the launch duration inside the timed region, where the kernels of the other batch in flight
                          # share the GPU; kernel_ms_alone is the same launch with nothing else running (three untimed steps)
@@ -626,17 +691,68 @@ def main():
                                             "frac": round(16.0 * W * H * B / (span_ms_sum / max(runs, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if span_ms_sum > 0 else None,
                                             "note": "not one kernel: remap inside the matcher would re-gather every pixel 3-4x in the VALU-critical kernel (DESIGN.md 3.3)"}},
         }
-        if world == 1 and not args.no_latency:
+        if world == 1 and probes and not args.no_latency:
             out["latency"] = single_pair_latency(lraw[0], rraw[0], calib, params, local_rank)
-        if world == 1 and not args.no_e2e:
+        if world == 1 and probes and not args.no_e2e:
             out["e2e"] = e2e_streaming(lraw, rraw, calib, params, local_rank)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out), flush=True)
     for p in pipes:
         p.close()
-    if world > 1:
-        dist.destroy_process_group()
+    del pipes, inputs, scenes_l, scenes_r
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(key, budget_s=5.0 if probes else 3.0)
+    return out
+
+
+def utest_timing_record(args, ctx, B=64, iters=60):
+    """The shape of the reference's only timing harness, DisparityTiming (reference test/UTest.cpp:400-429): 752x480, createStereoBM(48, 19),
+    the MATCHER ONLY on an already rectified pair (computeDisparityBare = block_matcher->compute: prefilter + match + L/R check + blanking),
+    here on B resident pairs per launch set.  CPU baseline = the oracle's cv::StereoBM::compute restatement on the same pairs."""
+    torch, dev = ctx["torch"], ctx["dev"]
+    from ros_gpu_stereo_processor_amd import kernels as K, synth
+    from oracle import oracle as O
+    w, h, nd, block = 752, 480, 48, 19
+    pairs = [synth.rectified_pair(w, h, nd, seed=300 + i)[:2] for i in range(4)]
+    L = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(B)])).to(dev)
+    R = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(B)])).to(dev)
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=block, min_disparity=0, num_disparities=nd, texture_threshold=10, uniqueness_ratio=15,
+              disp12_max_diff=1)
+    p = K.bm_params(**kw)
+    for _ in range(5):
+        d = K.stereobm(L, R, p)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(iters):
+        d = K.stereobm(L, R, p)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1) / iters
+    po = O.bm_params(**kw)
+    verified = None
+    if not args.no_verify:
+        got = d.cpu().numpy()
+        verified = all(bool(np.array_equal(got[i], O.stereobm(pairs[i][0], pairs[i][1], po, nthreads=1))) for i in range(4))
+    rec = {"workload": "utest_timing: 752x480 mono8 rectified pairs, ndisp=48 block=19, MATCHER ONLY (cv::StereoBM::compute: XSOBEL prefilter + SAD/WTA/uniqueness/sub-pixel + L/R check "
+                       "+ ROI blanking) -- the shape of the reference's DisparityTiming test (test/UTest.cpp:400-429)",
+           "value": round(B * iters / dt, 2), "unit": "stereo pairs/s", "ms_per_step": round(1e3 * dt / iters, 4), "pairs_per_step": B, "steps": iters, "verified": verified,
+           "roofline": {"bound": "hbm", "kernel": "gipk_stereobm launch set (k_prefilter_xsobel_pk x2, k_bm_c4<3,9,1>, k_bm_finalize_r)", "algorithmic_bytes_per_launch": 4.0 * w * h * B,
+                        "kernel_ms": round(gpu_ms, 4), "achieved": round(4.0 * w * h * B / (gpu_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(4.0 * w * h * B / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "valu_algorithmic": {"px_disp_pairs_per_s": round(w * h * nd * B / (gpu_ms * 1e-3), 1), "floor_slots_per_px_disp": VALU_FLOOR_SLOTS,
+                                             "peak_lane_slots_per_s": VALU_PEAK_LANE_SLOTS, "from": "kernel_ms (the whole launch set)",
+                                             "frac": round(w * h * nd * B / (gpu_ms * 1e-3) * VALU_FLOOR_SLOTS / VALU_PEAK_LANE_SLOTS, 4)}}}
+    if not args.no_cpu_baseline:
+        n, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 3.0:
+            O.stereobm(pairs[n % 4][0], pairs[n % 4][1], po, nthreads=1)
+            n += 1
+        secs = time.perf_counter() - t1
+        rec["cpu_baseline"] = {"value": round(n / secs, 2), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+                               "sample": "%d calls of the oracle's cv::StereoBM::compute restatement on the same 752x480 pairs in %.1f s, one thread" % (n, secs), "cpu_model": _cpu_model()}
+    return rec
 
 
 if __name__ == "__main__":
