@@ -106,6 +106,10 @@ struct gip_processor {
     std::vector<std::pair<void*, size_t>> pinned_pool;
     // batch pipeline
     DevBuf b_mono[2], b_color, b_rect[2], b_rect_color, b_f32;
+    // table of everything the cloud kernel derives from the disparity value alone (k_post.hip: gip_w_table_build), rebuilt when its key changes
+    DevBuf w_tab;
+    double w_key[6] = {0, 0, 0, 0, 0, 0};      // Q23, Q32, Q33, cx_l - cx_r, min_disparity, num_disparities
+    bool w_valid = false;
     // per-run timing events of the batch pipeline: 5 per run (bm0, bm1, total0, total1, end of rectify+prefilter+match+validate), grown on demand
     std::vector<hipEvent_t> tev;
     int timing_runs = 0;
@@ -385,7 +389,7 @@ int gip_destroy(gip_handle h)
             if (h->d_map1[i]) (void)hipFree(h->d_map1[i]);
             if (h->d_map2[i]) (void)hipFree(h->d_map2[i]);
         }
-    DevBuf* bufs[] = {&h->bm_scratch, &h->spk_scratch, &h->pc_dev, &h->b_mono[0], &h->b_mono[1], &h->b_color, &h->b_rect[0], &h->b_rect[1], &h->b_rect_color, &h->b_f32};
+    DevBuf* bufs[] = {&h->bm_scratch, &h->spk_scratch, &h->pc_dev, &h->b_mono[0], &h->b_mono[1], &h->b_color, &h->b_rect[0], &h->b_rect[1], &h->b_rect_color, &h->b_f32, &h->w_tab};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->tev)
@@ -1284,10 +1288,24 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
                                     h->spk_scratch.cap, B, npx * 2, st), "speckle");
     }
     // stage 5: float disparity (GPUStereoProcessor.cpp:320) + cloud (StereoProcessor.cpp:278-282, GpuSenderPc2.cpp) in one pass
-    if (d->disparity_f32 || want_pc)
-        B_STEP(gipk_disparity_outputs(d->disparity, (size_t)w * 2, rect_color, rect_color_cn == 1 ? rp : (size_t)w * 3, rect_color_cn, d->disparity_f32,
-                                      want_pc ? d->pointcloud : nullptr, w, hh, h->model.Q, h->model.left.cx(), h->model.right.cx(), bp.min_disparity, B, npx * 2,
-                                      rect_color_cn == 1 ? rplane : npx * 3, st), "disparity outputs");
+    if (d->disparity_f32 || want_pc) {
+        const void* tab = nullptr;
+#ifndef GIP_NO_W_TABLE
+        if (want_pc) {
+            const double key[6] = {h->model.Q[11], h->model.Q[14], h->model.Q[15], h->model.left.cx() - h->model.right.cx(), (double)bp.min_disparity, (double)bp.num_disparities};
+            if (!h->w_valid || std::memcmp(key, h->w_key, sizeof key) != 0) {
+                B_STEP(ensure_dev(h, h->w_tab, gip_w_table_bytes(bp.num_disparities)), "batch buffers");
+                B_STEP(gip_w_table_build(h->w_tab.p, h->model.Q, h->model.left.cx(), h->model.right.cx(), bp.min_disparity, bp.num_disparities, st), "disparity table");
+                std::memcpy(h->w_key, key, sizeof key);
+                h->w_valid = true;
+            }
+            tab = h->w_tab.p;
+        }
+#endif
+        B_STEP(gip_disparity_outputs_impl(d->disparity, (size_t)w * 2, rect_color, rect_color_cn == 1 ? rp : (size_t)w * 3, rect_color_cn, d->disparity_f32,
+                                          want_pc ? d->pointcloud : nullptr, w, hh, 0, h->model.Q, h->model.left.cx(), h->model.right.cx(), bp.min_disparity, B, npx * 2,
+                                          rect_color_cn == 1 ? rplane : npx * 3, st, tab, bp.num_disparities), "disparity outputs");
+    }
     H_HIP(h, hipEventRecord(ev[3], st));
     h->timing_runs++;
 #undef B_STEP

@@ -70,3 +70,11 @@ int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
                       void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx);
 // prefiltered planes inside a gipk_stereobm scratch buffer: pitch, per-image plane size, and the two base pointers
 void gip_stereobm_planes(void* scratch, int w, int h, int batch, uint8_t** left_f, uint8_t** right_f, size_t* pitch, size_t* plane);
+
+// Fused tail of the chain (float disparity + PointCloud2 records) with an optional table of everything that depends on the disparity value alone
+// (k_post.hip: gip_w_table_build; (ndisp + 1) * 16 + 1 entries of 16 bytes from FILTERED upwards).  Bit-identical with and without the table.
+size_t gip_w_table_bytes(int ndisp);
+int gip_w_table_build(void* table, const double Q[16], double cx_l, double cx_r, int min_disparity, int ndisp, gip_stream stream);
+int gip_disparity_outputs_impl(const int16_t* disp, size_t disp_pitch, const uint8_t* color, size_t color_pitch, int color_cn, float* f32_out, uint8_t* pc_out, int w, int h,
+                               int y_origin, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch, size_t disp_bstride, size_t color_bstride,
+                               gip_stream stream, const void* w_table, int table_ndisp);

@@ -51,6 +51,7 @@ struct Tile {
     uint8_t* pub_record = nullptr;                 // this tile's border record as the other tiles pull it
     uint8_t* records = nullptr;                    // the records of all n_tiles tiles: this tile's working copy (the union-find forest of its merge)
     int32_t* border_roots = nullptr;               // 2 w
+    void* w_tab = nullptr;                         // gip_w_table_build: what the cloud kernel derives from the disparity value alone
     float* f32 = nullptr;                          // own rows
     uint8_t* pc = nullptr;
     hipEvent_t ev_rect = nullptr, ev_rec = nullptr, ev_done = nullptr;   // cross-tile dependencies
@@ -301,8 +302,8 @@ int post_body(gip_rowsplit_s* rs, Tile& T)
             if (T.rect_color) { col = T.rect_color; cpitch = (size_t)w * 3; }
             else { col = T.rect + (size_t)(T.y0 - T.e0) * 2 * rs->rp; cpitch = 2 * rs->rp; cn = 1; }   // mono input: the rectified left rows, replicated (GRAY2BGR)
         }
-        RS_STEP(rs, gipk_disparity_outputs_rows(d_own, (size_t)w * 2, col, cpitch, cn, T.f32, T.pc, w, hown, T.y0, T.v.Q, T.v.cx_l, T.v.cx_r, rs->bp.min_disparity, 1, 0, 0, T.st),
-                "disparity outputs");
+        RS_STEP(rs, gip_disparity_outputs_impl(d_own, (size_t)w * 2, col, cpitch, cn, T.f32, T.pc, w, hown, T.y0, T.v.Q, T.v.cx_l, T.v.cx_r, rs->bp.min_disparity, 1, 0, 0, T.st,
+                                               T.w_tab, rs->bp.num_disparities), "disparity outputs");
     }
     return GIP_OK;
 }
@@ -363,7 +364,7 @@ void free_tile(Tile& T)
 {
     (void)hipSetDevice(T.device);
     if (T.st) (void)hipStreamSynchronize(T.st);
-    void* bufs[] = {T.own_raw[0], T.own_raw[1], T.mono[0], T.mono[1], T.color, T.rect, T.rect_color, T.bm_scratch, T.d_ext, T.spk_scratch, T.records, T.pub_record, T.border_roots,
+    void* bufs[] = {T.own_raw[0], T.own_raw[1], T.mono[0], T.mono[1], T.color, T.rect, T.rect_color, T.bm_scratch, T.d_ext, T.spk_scratch, T.records, T.pub_record, T.border_roots, T.w_tab,
                     T.f32, T.pc};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -474,6 +475,8 @@ int gip_rowsplit_open(const gip_camera_info* left, const gip_camera_info* right,
         }
         if (want_f32 || want_pc) ok = ok && hipMalloc((void**)&T.f32, (size_t)hown * w * 4) == hipSuccess;
         if (want_pc) ok = ok && hipMalloc((void**)&T.pc, (size_t)hown * w * 32) == hipSuccess;
+        if (want_pc) ok = ok && hipMalloc(&T.w_tab, gip_w_table_bytes(rs->bp.num_disparities)) == hipSuccess &&
+                          gip_w_table_build(T.w_tab, T.v.Q, T.v.cx_l, T.v.cx_r, rs->bp.min_disparity, rs->bp.num_disparities, T.st) == GIP_OK;
         ok = ok && hipEventCreateWithFlags(&T.ev_rect, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&T.ev_rec, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&T.ev_done, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 6; i++) ok = ok && hipEventCreate(&T.tev[i]) == hipSuccess;

@@ -779,10 +779,30 @@ __global__ void k_disp_outputs(const int16_t* __restrict__ disp, size_t dpitch, 
 // non-zero.  Dropping the zero terms changes no bit (x * +0.0 and + +0.0 are exact; the launcher also checks the zeros are
 // positive zeros) but more than halves the double-precision work.  This kernel runs next to the VALU-bound matcher of another batch, so its instruction count matters.
 constexpr int OUT_ROWS = 1;   // 4 rows per thread (64x4 blocks) halved the store bandwidth: a workgroup must write long contiguous runs
+// Everything the kernel derives from the disparity VALUE alone, tabulated once per (model, parameter) change: the float disparity, the
+// reciprocal of W = Q33 + Q32 d (an FP64 division per pixel otherwise) and Z.  One 16-byte load replaces them; the entries are computed
+// with the very expressions of the kernel, so the outputs are bit-identical (tests/test_gpu_kernels.py).  Index = d16 - lo.
+struct __attribute__((aligned(16))) WEntry { double iw; float z; float df; };
+__global__ void k_w_table(WEntry* __restrict__ tab, int n, int lo, QMat Q, float alpha, float beta, int filtered)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d16 = lo + i;
+    float df = (float)d16 * alpha;
+    df = df + beta;
+    const double d = df;
+    const double iW = 1. / (Q.q[15] + Q.q[14] * d);
+    double Z = Q.q[11] * iW;
+    if (d16 == filtered) Z = 10000.;
+    tab[i].iw = iW;
+    tab[i].z = (float)Z;
+    tab[i].df = df;
+}
+
 template <int CN>
 __global__ void k_disp_outputs_sq(const int16_t* __restrict__ disp, size_t dpitch, const uint8_t* __restrict__ col, size_t cpitch,
                                   float* __restrict__ f32out, uint8_t* __restrict__ pc, int w, int h, QMat Q, float alpha, float beta, int filtered,
-                                  size_t dbs, size_t cbs, size_t fbs, size_t obs, int y_org)
+                                  size_t dbs, size_t cbs, size_t fbs, size_t obs, int y_org, const WEntry* __restrict__ tab, int tab_lo, int tab_n)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = (blockIdx.y * blockDim.y + threadIdx.y) * OUT_ROWS;
     if (x >= w || y0 >= h) return;
@@ -806,12 +826,20 @@ __global__ void k_disp_outputs_sq(const int16_t* __restrict__ disp, size_t dpitc
     for (int j = 0; j < OUT_ROWS; j++) {
         const int y = y0 + j;
         if (y >= h) break;
+        const double qy = q[5] * (y + y_org) + q[7];
+        const unsigned ti = (unsigned)(d16[j] - tab_lo);
+        if (tab && ti < (unsigned)tab_n) {
+            const WEntry e = tab[ti];
+            if (f32out) ((float*)((uint8_t*)f32out + blockIdx.z * fbs))[(size_t)y * w + x] = e.df;
+            if (!pc) continue;
+            store_pc2_record(pc + blockIdx.z * obs + ((size_t)y * w + x) * 32, (float)(qx * e.iw), (float)(qy * e.iw), e.z, c[j]);
+            continue;
+        }
         float df = (float)d16[j] * alpha;
         df = df + beta;
         if (f32out) ((float*)((uint8_t*)f32out + blockIdx.z * fbs))[(size_t)y * w + x] = df;
         if (!pc) continue;
         const double d = df;
-        const double qy = q[5] * (y + y_org) + q[7];
         const double iW = 1. / (q[15] + q[14] * d);
         const double X = qx * iW, Y = qy * iW;
         double Z = q[11] * iW;
@@ -1070,6 +1098,31 @@ int gipk_disparity_outputs_rows(const int16_t* disp, size_t disp_pitch, const ui
                                 uint8_t* pc_out, int w, int h, int y_origin, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch,
                                 size_t disp_bstride, size_t color_bstride, gip_stream stream)
 {
+    return gip_disparity_outputs_impl(disp, disp_pitch, color, color_pitch, color_cn, f32_out, pc_out, w, h, y_origin, Q, cx_l, cx_r, min_disparity, batch, disp_bstride,
+                                      color_bstride, stream, nullptr, 0);
+}
+
+}  // extern "C"
+
+size_t gip_w_table_bytes(int ndisp) { return ndisp > 0 ? (size_t)((ndisp + 1) * 16 + 1) * sizeof(WEntry) : 0; }
+
+int gip_w_table_build(void* table, const double Q[16], double cx_l, double cx_r, int min_disparity, int ndisp, gip_stream stream)
+{
+    GIPK_ARGCHECK(table && Q && ndisp > 0 && ((uintptr_t)table & 15) == 0);
+    QMat q;
+    for (int i = 0; i < 16; i++) q.q[i] = Q[i];
+    const int n = (ndisp + 1) * 16 + 1, lo = (min_disparity - 1) * 16;
+    hipLaunchKernelGGL(k_w_table, dim3(gip_div_up(n, TPB)), dim3(TPB), 0, (hipStream_t)stream, (WEntry*)table, n, lo, q, (float)(1.0 / 16), (float)(-(cx_l - cx_r)), lo);
+    GIP_LAUNCH_CHECK();
+    return GIP_OK;
+}
+
+// w_table (optional): gip_w_table_build's output for the same Q, cx, min_disparity and `table_ndisp` disparities -- used by the kernel for the
+// sparse Q of a rectified pair; a disparity outside the table's range falls back to the arithmetic
+int gip_disparity_outputs_impl(const int16_t* disp, size_t disp_pitch, const uint8_t* color, size_t color_pitch, int color_cn, float* f32_out, uint8_t* pc_out, int w, int h,
+                               int y_origin, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch, size_t disp_bstride, size_t color_bstride,
+                               gip_stream stream, const void* w_table, int table_ndisp)
+{
     GIPK_ARGCHECK(disp && Q && (f32_out || pc_out) && w > 0 && h > 0 && batch > 0 && disp_pitch % 2 == 0);
     GIPK_ARGCHECK(!pc_out || ((uintptr_t)pc_out & 15) == 0);
     GIPK_ARGCHECK(!color || color_cn == 1 || color_cn == 3);
@@ -1081,18 +1134,22 @@ int gipk_disparity_outputs_rows(const int16_t* disp, size_t disp_pitch, const ui
     bool stereo_q = true;
     for (int i : {1, 2, 4, 6, 8, 9, 10, 12, 13}) stereo_q = stereo_q && Q[i] == 0.0 && !std::signbit(Q[i]);
 #define GIP_OUT_ARGS disp, disp_pitch / 2, color, color_pitch, f32_out, pc_out, w, h, q, alpha, beta, (min_disparity - 1) * 16, disp_bstride, color_bstride, npx * 4, npx * 32, y_origin
+#define GIP_TAB_ARGS (const WEntry*)w_table, (min_disparity - 1) * 16, w_table ? (table_ndisp + 1) * 16 + 1 : 0
     const dim3 g4(gip_div_up(w, TPB), gip_div_up(h, OUT_ROWS), batch), b4(TPB, 1);
     if (color && color_cn == 1) {
-        if (stereo_q) hipLaunchKernelGGL(k_disp_outputs_sq<1>, g4, b4, 0, (hipStream_t)stream, GIP_OUT_ARGS);
+        if (stereo_q) hipLaunchKernelGGL(k_disp_outputs_sq<1>, g4, b4, 0, (hipStream_t)stream, GIP_OUT_ARGS, GIP_TAB_ARGS);
         else hipLaunchKernelGGL(k_disp_outputs<1>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, GIP_OUT_ARGS);
     } else {
-        if (stereo_q) hipLaunchKernelGGL(k_disp_outputs_sq<3>, g4, b4, 0, (hipStream_t)stream, GIP_OUT_ARGS);
+        if (stereo_q) hipLaunchKernelGGL(k_disp_outputs_sq<3>, g4, b4, 0, (hipStream_t)stream, GIP_OUT_ARGS, GIP_TAB_ARGS);
         else hipLaunchKernelGGL(k_disp_outputs<3>, grid2d(w, h, batch), dim3(TPB), 0, (hipStream_t)stream, GIP_OUT_ARGS);
     }
 #undef GIP_OUT_ARGS
+#undef GIP_TAB_ARGS
     GIP_LAUNCH_CHECK();
     return GIP_OK;
 }
+
+extern "C" {
 
 int gipk_disparity_to_pointcloud2(const int16_t* disp, size_t disp_pitch, const uint8_t* bgr, size_t bgr_pitch, uint8_t* out, int w, int h,
                                   const double Q[16], double cx_l, double cx_r, int min_disparity, int batch, size_t disp_bstride, size_t bgr_bstride,

@@ -157,6 +157,37 @@ int main(int argc, char **argv)
         for (int s2 = 0; s2 < 2; s2++)
             for (size_t k = 0; k < order[s2].size(); k++) CHECK(order[s2][k] == k);      // each handle delivers in submission order
     }
+    // One frame cut into THREE row tiles (RowSplitStereo: one handle per tile, halo rows by peer copy, border components merged on the device)
+    // must give exactly what the synchronous single-handle schedule produced above.
+    {
+        Mat l = read_raw(dir + "/left_raw.bin", 480, 752, GIP_8UC1), r = read_raw(dir + "/right_raw.bin", 480, 752, GIP_8UC1);
+        std::ifstream f16(dir + "/out_disp16.bin", std::ios::binary), f32(dir + "/out_disp32.bin", std::ios::binary), fc(dir + "/out_cloud.bin", std::ios::binary);
+        std::vector<int16_t> exp16((size_t)480 * 752);
+        std::vector<float> exp32((size_t)480 * 752);
+        std::vector<unsigned char> expc((size_t)480 * 752 * 32);
+        f16.read((char *)exp16.data(), (std::streamsize)(exp16.size() * 2));
+        f32.read((char *)exp32.data(), (std::streamsize)(exp32.size() * 4));
+        fc.read((char *)expc.data(), (std::streamsize)expc.size());
+        gip_camera_info li, ri;
+        char name[64];
+        CHECK(gip_read_calibration((dir + "/left.yaml").c_str(), &li, name, sizeof name) == GIP_OK);
+        CHECK(gip_read_calibration((dir + "/right.yaml").c_str(), &ri, name, sizeof name) == GIP_OK);
+        gip_bm_params p{};
+        p.prefilter_type = GIP_PREFILTER_XSOBEL; p.prefilter_size = 5; p.prefilter_cap = 31; p.block_size = 15; p.min_disparity = 0; p.num_disparities = 64;
+        p.texture_threshold = 10; p.uniqueness_ratio = 0; p.disp12_max_diff = 0;
+        RowSplitStereo split(3, li, ri, p, 100, 2.0, 752, 480, "mono8", GIP_TOPIC_DISPARITY | GIP_TOPIC_POINTCLOUD);
+        CHECK(split.tiles() == 3);
+        for (int rep = 0; rep < 2; rep++) {
+            Mat d16, d32;
+            std::vector<uint8_t> cloud;
+            split.imageCb(l, r, &d16, &d32, &cloud);
+            CHECK(std::memcmp(d16.data, exp16.data(), exp16.size() * 2) == 0);
+            CHECK(std::memcmp(d32.data, exp32.data(), exp32.size() * 4) == 0);
+            CHECK(std::memcmp(cloud.data(), expc.data(), expc.size()) == 0);
+        }
+        const std::vector<gip_rowsplit_timing> tm = split.profileSerial();
+        CHECK(tm.size() == 3 && tm[1].match_ms > 0.f && tm[1].total_ms >= tm[1].match_ms);
+    }
     std::puts("cpp tests ok");
     return 0;
 }

@@ -324,3 +324,34 @@ def test_nccl_broadcast_and_halo_exchange_two_devices(gpu):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (the driver's 8-GPU node runs the N > 1 bench)")
     _run_selftest(2, 29517, rehearse=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd,mind", [(64, 0), (48, 5)])
+def test_cloud_table_is_bit_identical_to_the_arithmetic(gpu, nd, mind):
+    """The batch pipeline's cloud kernel reads 1 / (Q33 + Q32 d), Z and the float disparity from a table indexed by the disparity value
+    (gip_w_table_build, k_post.hip); the stateless launcher gipk_disparity_outputs computes them per pixel.  Same expressions, so the same
+    bytes: float disparity and every one of the 32 bytes of every PointCloud2 record."""
+    import torch
+    from ros_gpu_stereo_processor_amd import capi, kernels as K
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+    w, h, B = 416, 160, 2
+    calib = synth.scaled_calibration(w, h)
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=9, min_disparity=mind, num_disparities=nd, texture_threshold=10,
+              uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    raws = [synth.raw_pair(w, h, nd, seed=70 + i, calib=calib)[:2] for i in range(B)]
+    L = torch.from_numpy(np.stack([r[0] for r in raws])).to(gpu)
+    R = torch.from_numpy(np.stack([r[1] for r in raws])).to(gpu)
+    pipe = BatchPipeline(w, h, calib, capi.BMParams(**kw), B, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 0, 100, 2.0)
+    maps = pipe.host_maps_to_device()
+    pipe.install_maps(maps)
+    pipe.run(L, R)
+    torch.cuda.synchronize()
+    m = pipe.proc.model()
+    rect_l = K.remap(L, maps[0], maps[1])
+    for b in range(B):
+        f32, pc = K.disparity_outputs(pipe.disparity[b].contiguous(), rect_l[b].contiguous(), np.array(m["Q"], np.float64).reshape(4, 4), m["cx_l"], m["cx_r"], mind)
+        assert torch.equal(f32, pipe.disparity_f32[b])
+        assert torch.equal(pc, pipe.pointcloud[b])
+        assert (pipe.disparity[b] != (mind - 1) * 16).float().mean() > 0.2
+    pipe.close()
