@@ -185,13 +185,40 @@ def single_pair_latency(lraw, rraw, calib, params, device, iters=30):
             "what": "gip_process_pair (imageCb schedule: upload L/R, mono, rectify L/R + colour L, StereoBM, speckle, reproject) for one %dx%d pair, host wall time incl. sync" % (W, H)}
 
 
+E2E_MODES = None     # experiment hook (tools/e2e_probe.py): [(mode, frames_per_batch, compute_lanes), ...]
 PCIE_GBS = 63.0  # /opt/skills/guides/MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec, per direction)
+
+
+def measured_link_gbs(device, mb=256, reps=6):
+    """What the host link of this box moves: one large pinned copy per direction alone, and both directions at once (GB/s)."""
+    import torch
+    dev = torch.device("cuda", device)
+    n = mb << 20
+    hin, hout = torch.empty(n, dtype=torch.uint8).pin_memory(), torch.empty(n, dtype=torch.uint8).pin_memory()
+    din, dout = torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    def run(h2d, d2h):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if h2d:
+                with torch.cuda.stream(s1):
+                    din.copy_(hin, non_blocking=True)
+            if d2h:
+                with torch.cuda.stream(s2):
+                    hout.copy_(dout, non_blocking=True)
+        torch.cuda.synchronize()
+        return reps * n / (time.perf_counter() - t0) / 1e9
+    run(True, True)
+    a, b, c = run(True, False), run(False, True), run(True, True)
+    return {"h2d": round(a, 1), "d2h": round(b, 1), "h2d_duplex": round(c, 1), "d2h_duplex": round(c, 1), "what": "%d MB pinned copies, %d per direction; duplex = each direction's rate with both running" % (mb, reps)}
 
 
 def e2e_streaming(lraw, rraw, calib, params, device, budget_s=1.5):
     """End-to-end pairs/s through the streaming C-ABI (gip_streamer_*): every pair starts as two raw images in pageable host memory
-    and ends as delivered outputs in pinned host memory -- pinned ring, H2D / compute / D2H on three HIP streams, 3 batches in flight,
-    hipLaunchHostFunc delivery.  Each record names its PCIe bound.  Not part of `value`."""
+    and ends as delivered outputs in pinned host memory -- pinned ring, copy-in stream, compute stream, copy-out stream, hipLaunchHostFunc
+    delivery; the caller submits pair by pair.  Each record names its PCIe bound.  Not part of `value`."""
     from ros_gpu_stereo_processor_amd import capi
     from ros_gpu_stereo_processor_amd import processor as P
     from ros_gpu_stereo_processor_amd.streamer import Streamer
@@ -204,35 +231,43 @@ def e2e_streaming(lraw, rraw, calib, params, device, budget_s=1.5):
     proc.setMaxSpeckleDiff(SPECKLE_DIFF)
     out = []
     nsrc = len(lraw)
-    import torch
-    keep = [torch.from_numpy(np.ascontiguousarray(x)).pin_memory() for x in list(lraw) + list(rraw)]      # pinned copies of the source frames
-    pin_l, pin_r = [k.numpy() for k in keep[:nsrc]], [k.numpy() for k in keep[nsrc:]]
     for name, outputs, out_bytes in (("raw H2D + f32 disparity D2H", capi.TOPIC_DISPARITY, 4 * px),
                                      ("raw H2D + f32 disparity + 32-B PointCloud2 D2H", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 36 * px)):
-        for fpb, pinned in ((1, False), (16, False), (64, False)):
-            src_l, src_r = (pin_l, pin_r) if pinned else (lraw, rraw)
-            st = Streamer(proc, W, H, ENCODING, outputs, depth=3, frames_per_batch=fpb, inputs_pinned=pinned)
-            for i in range(3 * fpb):          # warm-up: every ring slot used once
-                st.submit(src_l[i % nsrc], src_r[i % nsrc])
+        # adaptive: the caller submits PAIR BY PAIR and the streamer forms the batches (a partly filled batch is launched whenever a compute lane is
+        # free); fixed: full batches of 1 / 64 pairs only (the round-2 behaviour, for comparison)
+        for mode, fpb, lanes in E2E_MODES if E2E_MODES else (("adaptive", 0, 1), ("fixed", 1, 1), ("fixed", 64, 1)):
+            st = Streamer(proc, W, H, ENCODING, outputs, frames_per_batch=fpb, adaptive=(mode == "adaptive"), compute_lanes=lanes)
+            warm = 200 if mode == "adaptive" else 4 * max(fpb, 1)
+            for i in range(warm):          # warm-up: every ring slot used
+                st.submit(lraw[i % nsrc], rraw[i % nsrc])
             st.flush()
+            l0 = st.launches()
             n, t0 = 0, time.perf_counter()
             while True:
-                for i in range(fpb):
-                    st.submit(src_l[(n + i) % nsrc], src_r[(n + i) % nsrc])
-                n += fpb
+                for i in range(64):
+                    st.submit(lraw[(n + i) % nsrc], rraw[(n + i) % nsrc])
+                n += 64
                 if time.perf_counter() - t0 > budget_s / 4:
                     break
             st.flush()
             dt = time.perf_counter() - t0
-            assert st.delivered() == n + 3 * fpb
+            assert st.delivered() == n + warm
+            nl = st.launches() - l0
             st.close()
             in_bytes = 2 * px * cn
             bound = PCIE_GBS * 1e9 / max(in_bytes, out_bytes)     # full duplex: the larger direction binds
-            out.append({"what": name, "pairs_per_batch": fpb, "host_input": "pinned, read in place" if pinned else "pageable, copied into the pinned ring by the submitting thread", "batches_in_flight": 3, "pairs": n, "pairs_per_s": round(n / dt, 1), "ms_per_pair": round(1e3 * dt / n, 4),
+            out.append({"what": name, "batching": mode, "max_pairs_per_launch": fpb if fpb else "auto", "avg_pairs_per_launch": round(n / max(nl, 1), 2),
+                        "host_input": "pageable, submitted pair by pair, copied into the pinned ring by the submitting thread",
+                        "compute_lanes": lanes, "pairs": n, "pairs_per_s": round(n / dt, 1), "ms_per_pair": round(1e3 * dt / n, 4),
                         "h2d_bytes_per_pair": in_bytes, "d2h_bytes_per_pair": out_bytes, "pcie_bound_pairs_per_s": round(bound, 1),
                         "frac_of_pcie_bound": round(n / dt / bound, 4)})
     proc.close()
-    return {"api": "gip_streamer_open/submit/flush (pinned ring, 3 HIP streams, hipLaunchHostFunc delivery)", "pcie_gbs_spec_per_direction": PCIE_GBS,
+    link = measured_link_gbs(device)
+    for r in out:
+        # against what this box's link really moves in the binding direction (one large pinned copy per direction, both at once)
+        r["frac_of_measured_link"] = round(r["pairs_per_s"] * max(r["h2d_bytes_per_pair"], r["d2h_bytes_per_pair"]) / 1e9 /
+                                           (link["d2h_duplex"] if r["d2h_bytes_per_pair"] >= r["h2d_bytes_per_pair"] else link["h2d_duplex"]), 4)
+    return {"measured_link_gbs": link, "api": "gip_streamer_open/submit/flush (pinned ring filled with streaming stores, copy-in / compute / copy-out streams, adaptive batching, hipLaunchHostFunc delivery)", "pcie_gbs_spec_per_direction": PCIE_GBS,
             "records": out}
 
 

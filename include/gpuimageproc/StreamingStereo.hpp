@@ -33,9 +33,10 @@ class StreamingStereo
     typedef std::function<void(const gip_streamer_result &)> ResultCb;
 
     // processor: model and parameters set; outputs: GIP_TOPIC_DISPARITY and/or GIP_TOPIC_POINTCLOUD
-    StreamingStereo(GpuStereoProcessor &processor, int width, int height, const std::string &encoding, uint32_t outputs, ResultCb cb, int depth = 3,
-                    int frames_per_batch = 1, bool want_disparity16 = false)
-        : cb_(std::move(cb))
+    // depth / frames_per_batch 0 = automatic; adaptive: the streamer forms the batches from pair-by-pair submissions (gip_streamer_config::batching)
+    StreamingStereo(GpuStereoProcessor &processor, int width, int height, const std::string &encoding, uint32_t outputs, ResultCb cb, int depth = 0,
+                    int frames_per_batch = 0, bool want_disparity16 = false, bool adaptive = true)
+        : cb_(std::move(cb)), width_(width), height_(height)
     {
         gip_streamer_config cfg{};
         cfg.width = width;
@@ -45,6 +46,8 @@ class StreamingStereo
         cfg.want_disparity16 = want_disparity16 ? 1 : 0;
         cfg.depth = depth;
         cfg.frames_per_batch = frames_per_batch;
+        cfg.batching = adaptive ? 0 : 1;
+        channels_ = (cfg.encoding == 1 || cfg.encoding == 2) ? 3 : 1;
         int rc = gip_streamer_open(processor.handle(), &cfg, &StreamingStereo::trampoline, this, &s_);
         if (rc != GIP_OK) throw std::runtime_error(std::string("gip_streamer_open: ") + gip_status_string(rc));
     }
@@ -56,7 +59,14 @@ class StreamingStereo
     StreamingStereo &operator=(const StreamingStereo &) = delete;
 
     // the streaming imageCb: returns as soon as the pair is in the ring (blocks only when every ring slot is in flight)
-    void imageCb(const Mat &l_raw, const Mat &r_raw, const gip_header &header) { ck(gip_streamer_submit(s_, l_raw.data, r_raw.data, l_raw.step, &header)); }
+    void imageCb(const Mat &l_raw, const Mat &r_raw, const gip_header &header)
+    {
+        // gip_streamer_submit reads height x width x channels bytes from both pointers: a wrong-size Mat would be an out-of-bounds read
+        if (l_raw.rows != height_ || l_raw.cols != width_ || r_raw.rows != height_ || r_raw.cols != width_ || l_raw.channels() != channels_ || r_raw.channels() != channels_ ||
+            l_raw.elemSize() != (size_t)channels_ || r_raw.elemSize() != (size_t)channels_ || l_raw.step != r_raw.step || !l_raw.data || !r_raw.data)
+            throw std::runtime_error("StreamingStereo::imageCb: image size / type differs from the streamer's configuration");
+        ck(gip_streamer_submit(s_, l_raw.data, r_raw.data, l_raw.step, &header));
+    }
     void flush() { ck(gip_streamer_flush(s_)); }
     uint64_t delivered() const { return gip_streamer_delivered(s_); }
 
@@ -72,6 +82,7 @@ class StreamingStereo
     }
     gip_streamer s_ = nullptr;
     ResultCb cb_;
+    int width_ = 0, height_ = 0, channels_ = 1;
 };
 
 // One processor + streamer per device; frame i -> device i mod N.  With fewer devices than `n_handles` the handles share devices
@@ -82,8 +93,8 @@ class MultiDeviceStereo
     typedef std::function<void(int device_slot, const gip_streamer_result &)> ResultCb;
 
     MultiDeviceStereo(int n_handles, const gip_camera_info &left, const gip_camera_info &right, const gip_bm_params &params, int max_speckle_size,
-                      double max_speckle_diff, int width, int height, const std::string &encoding, uint32_t outputs, ResultCb cb, int depth = 3,
-                      int frames_per_batch = 1)
+                      double max_speckle_diff, int width, int height, const std::string &encoding, uint32_t outputs, ResultCb cb, int depth = 0,
+                      int frames_per_batch = 0)
     {
         const int ndev = gip_device_count();
         if (ndev <= 0) throw std::runtime_error("MultiDeviceStereo: no HIP device");

@@ -270,22 +270,30 @@ int64_t gip_ros1_serialize_pointcloud2(const gip_pointcloud2_msg *msg, uint8_t *
  * The host link of the nodelet: the reference uploads both raws per frame (src/StereoProcessor.cpp:179-180), runs the chain,
  * hands every output to a stream host callback (src/GpuSenderIfc.cpp:13-26) and then BLOCKS on waitForAllStreams()
  * (src/StereoProcessor.cpp:284), i.e. one frame in flight.  The streamer keeps `depth` batches in flight instead: a ring of
- * pinned input / output buffers, hipMemcpyAsync H2D on a copy-in stream, the chain (gip_batch_run) on a compute stream, D2H on a
- * copy-out stream, delivery through hipLaunchHostFunc on the copy-out stream.  Upload of frame i+1, compute of frame i and
- * download of frame i-1 overlap; gip_streamer_submit blocks only when every ring slot is still in flight (back-pressure).
- * The processor handle must have its model and parameters set; it must not be used for anything else while a streamer is open. */
+ * pinned input / output buffers, hipMemcpyAsync H2D on a copy-in stream, the chain (gip_batch_run) on `compute_lanes` compute streams whose
+ * SAD matchers share one stream, D2H on a copy-out stream, delivery through hipLaunchHostFunc on the copy-out stream.  Upload of frame i+1,
+ * compute of frames i and i-1 and download of frame i-2 overlap; gip_streamer_submit blocks only when every ring slot is still in flight
+ * (back-pressure).
+ * The caller submits pair by pair and never chooses a batch size (batching 0, the default): a pair joins the batch being filled, and that
+ * batch is launched as soon as a compute lane is free (or it is full) -- batches of one pair and minimal latency for a camera, batches that
+ * grow until the launch overhead is amortised for a bag replay.
+ * The processor handle must have its model and parameters set; it must not be used for anything else, nor have its parameters changed,
+ * while a streamer is open (the other compute lanes run on clones of it made at open). */
 typedef struct gip_streamer_s *gip_streamer;
 typedef struct gip_streamer_config {
     int32_t width, height;
     int32_t encoding;        /* as gip_batch_desc::encoding */
     uint32_t outputs;        /* GIP_TOPIC_DISPARITY (float disparity, 4 B/px) and/or GIP_TOPIC_POINTCLOUD (32 B/px) delivered */
     int32_t want_disparity16;/* also deliver the int16 x16 map (2 B/px) */
-    int32_t depth;           /* ring slots = batches in flight (>= 2; 0 -> 3) */
-    int32_t frames_per_batch;/* stereo pairs per compute launch (>= 1; 0 -> 1).  1 = lowest latency; larger batches fill the GPU
-                              * (a single 1242x375 pair occupies a tenth of it) at the price of batch latency */
+    int32_t depth;           /* ring slots = batches in flight (>= 2; 0 -> compute_lanes + 2) */
+    int32_t frames_per_batch;/* CAPACITY of a ring slot = the most pairs one launch set processes (0 -> automatic: as many as keep a slot's
+                              * largest buffer near 256 MB, at most 64).  With batching 1 it is the fixed batch size (0 -> 1) */
     int32_t inputs_pinned;   /* 1: the raw images passed to gip_streamer_submit live in pinned (hipHostMalloc / hipHostRegister) memory with
                               * tight rows and stay valid until their pair has been delivered: the H2D copy then reads them in place and the
                               * submitting thread copies nothing */
+    int32_t batching;        /* 0 (default): adaptive -- a partly filled batch is launched whenever fewer than compute_lanes batches are
+                              * computing; 1: fixed -- only full batches are launched (a partial one by gip_streamer_flush) */
+    int32_t compute_lanes;   /* batches computing concurrently, each on its own stream and processor handle (0 -> 2; 1..4) */
 } gip_streamer_config;
 typedef struct gip_streamer_result {
     uint64_t seq;                 /* submission index of this pair (0, 1, ...) */
@@ -299,12 +307,16 @@ typedef struct gip_streamer_result {
 typedef void (*gip_streamer_cb)(const gip_streamer_result *result, void *user);
 
 int gip_streamer_open(gip_handle h, const gip_streamer_config *cfg, gip_streamer_cb cb, void *user, gip_streamer *out);
-/* copies both raw images (rows `step` bytes apart; 0 = tight) into the ring and returns; a partial batch is launched by flush */
+/* copies both raw images (rows `step` bytes apart; 0 = tight) into the ring and returns.  After a failed launch (a HIP error, or a
+ * parameter block gip_batch_run rejects) the streamer is in a STICKY error state: everything is drained, the pairs that were queued are
+ * lost, and submit / flush return that error from then on (close and reopen). */
 int gip_streamer_submit(gip_streamer s, const void *left_raw, const void *right_raw, size_t step, const gip_header *header);
 /* launch a partially filled batch and wait until every submitted pair has been delivered */
 int gip_streamer_flush(gip_streamer s);
 /* pairs delivered so far (callback returned) */
 uint64_t gip_streamer_delivered(gip_streamer s);
+/* launch sets issued so far (pairs submitted / launches = the average batch the adaptive policy formed) */
+uint64_t gip_streamer_launches(gip_streamer s);
 int gip_streamer_close(gip_streamer s);
 const char *gip_streamer_last_error(gip_streamer s);
 

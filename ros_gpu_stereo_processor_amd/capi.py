@@ -87,7 +87,7 @@ class BatchDesc(C.Structure):
 
 class StreamerConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32), ("want_disparity16", C.c_int32),
-                ("depth", C.c_int32), ("frames_per_batch", C.c_int32), ("inputs_pinned", C.c_int32)]
+                ("depth", C.c_int32), ("frames_per_batch", C.c_int32), ("inputs_pinned", C.c_int32), ("batching", C.c_int32), ("compute_lanes", C.c_int32)]
 
 
 class StreamerResult(C.Structure):
@@ -204,6 +204,7 @@ PROTOTYPES = {
     "gip_streamer_submit": (_i, [_vp, _vp, _vp, _sz, C.POINTER(Header)]),
     "gip_streamer_flush": (_i, [_vp]),
     "gip_streamer_delivered": (C.c_uint64, [_vp]),
+    "gip_streamer_launches": (C.c_uint64, [_vp]),
     "gip_streamer_close": (_i, [_vp]),
     "gip_streamer_last_error": (C.c_char_p, [_vp]),
     "gipk_disparity_outputs_rows": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp, _i, _i, _i, C.POINTER(_d), _d, _d, _i, _i, _sz, _sz, _vp]),

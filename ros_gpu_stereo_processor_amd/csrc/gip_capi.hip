@@ -152,9 +152,9 @@ int ensure_dev(gip_handle h, DevBuf& b, size_t bytes)
 {
     if (b.cap >= bytes) return GIP_OK;
     if (b.p) {
-        // the buffer may still be in use by queued work
-        H_HIP(h, hipStreamSynchronize(h->l_strm));
-        H_HIP(h, hipStreamSynchronize(h->r_strm));
+        // the buffer may still be in use by queued work (a clone has no side streams: hipFree itself waits for the device)
+        if (h->l_strm) H_HIP(h, hipStreamSynchronize(h->l_strm));
+        if (h->r_strm) H_HIP(h, hipStreamSynchronize(h->r_strm));
         H_HIP(h, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -512,6 +512,37 @@ int gip_handle_view(gip_handle h, GipHandleView* v)
     v->params = h->params;
     v->max_speckle_size = h->max_speckle_size;
     v->max_speckle_diff = h->max_speckle_diff;
+    return GIP_OK;
+}
+
+int gip_handle_clone(gip_handle src, gip_handle* out)
+{
+    if (!src || !out) return GIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!src->model.initialised || !src->d_map1[0]) return fail(src, GIP_ERR_NOT_INITIALISED, "stereo model not initialised");
+    gip_handle h = nullptr;
+    int rc = gip_create(src->device, &h);
+    if (rc != GIP_OK) return rc;
+    h->model = src->model;
+    h->params = src->params;
+    h->max_speckle_size = src->max_speckle_size;
+    h->max_speckle_diff = src->max_speckle_diff;
+    h->refine_disparity = src->refine_disparity;
+    h->l_cam_name = src->l_cam_name;
+    h->r_cam_name = src->r_cam_name;
+    for (int i = 0; i < 2; i++) {
+        h->d_map1[i] = src->d_map1[i];
+        h->d_map2[i] = src->d_map2[i];
+    }
+    h->maps_owned = false;
+    h->map_w = src->map_w;
+    h->map_h = src->map_h;
+    // A clone only ever runs gip_batch_run on the caller's streams: give its two side streams back.  The runtime multiplexes all streams
+    // of a process onto a handful of hardware queues; streams that share a queue serialise, so idle streams are not free (gip_streamer.cpp).
+    (void)hipStreamDestroy(h->l_strm);
+    (void)hipStreamDestroy(h->r_strm);
+    h->l_strm = h->r_strm = nullptr;
+    *out = h;
     return GIP_OK;
 }
 

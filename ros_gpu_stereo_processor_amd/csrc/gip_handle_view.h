@@ -16,3 +16,8 @@ struct GipHandleView {
 };
 
 int gip_handle_view(gip_handle h, GipHandleView* out);
+
+// A second handle on the same device with the same model, parameters and speckle settings that SHARES the source's device-resident
+// rectification tables (the source must outlive the clone).  For pipelines that keep several batches in flight: gip_batch_run's scratch
+// buffers belong to the handle, so every batch in flight needs a handle of its own (gip_streamer.cpp).
+int gip_handle_clone(gip_handle src, gip_handle* out);

@@ -11,15 +11,19 @@ from .pipeline import ENCODINGS
 
 
 class Streamer:
-    def __init__(self, proc, width, height, encoding="mono8", outputs=capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, want_disparity16=False, depth=3,
-                 frames_per_batch=1, on_result=None, inputs_pinned=False):
+    def __init__(self, proc, width, height, encoding="mono8", outputs=capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, want_disparity16=False, depth=0,
+                 frames_per_batch=0, on_result=None, inputs_pinned=False, adaptive=True, compute_lanes=0):
         """proc: a GpuStereoProcessor with model and parameters set.  on_result(seq, header, d16, f32, cloud): called per pair with
         numpy COPIES (None for outputs not requested).  inputs_pinned: the arrays given to submit() are views of pinned memory (e.g.
-        torch.from_numpy(x).pin_memory().numpy()) that stay alive until delivered; they are then read in place by the H2D copy."""
+        torch.from_numpy(x).pin_memory().numpy()) that stay alive until delivered; they are then read in place by the H2D copy.
+        adaptive (default): pairs are submitted one by one and the streamer forms the batches (frames_per_batch = the most pairs per launch,
+        0 = automatic); adaptive=False: fixed batches of frames_per_batch pairs."""
         self._lib = capi.lib()
         self.proc = proc
         self.w, self.h = width, height
-        cfg = capi.StreamerConfig(width, height, ENCODINGS[encoding], outputs, 1 if want_disparity16 else 0, depth, frames_per_batch, 1 if inputs_pinned else 0)
+        self.channels = 3 if encoding in ("bgr8", "rgb8") else 1
+        cfg = capi.StreamerConfig(width, height, ENCODINGS[encoding], outputs, 1 if want_disparity16 else 0, depth, frames_per_batch, 1 if inputs_pinned else 0,
+                                  0 if adaptive else 1, compute_lanes)
         self._on_result = on_result
         self._errors = []
 
@@ -46,7 +50,10 @@ class Streamer:
             raise capi.GipError(rc, self._lib.gip_streamer_last_error(self._s).decode())
 
     def submit(self, left, right, header=None):
-        assert left.flags["C_CONTIGUOUS"] and right.flags["C_CONTIGUOUS"] and left.dtype == np.uint8 and left.shape == right.shape
+        shape = (self.h, self.w) if self.channels == 1 else (self.h, self.w, self.channels)
+        if left.shape != shape or right.shape != shape or left.dtype != np.uint8 or right.dtype != np.uint8:
+            raise ValueError("Streamer.submit: images must be uint8 of shape %r (got %r / %r)" % (shape, left.shape, right.shape))
+        assert left.flags["C_CONTIGUOUS"] and right.flags["C_CONTIGUOUS"]
         self._check(self._lib.gip_streamer_submit(self._s, left.ctypes.data, right.ctypes.data, 0, C.byref(header) if header is not None else None))
 
     def flush(self):
@@ -56,6 +63,9 @@ class Streamer:
 
     def delivered(self):
         return int(self._lib.gip_streamer_delivered(self._s))
+
+    def launches(self):
+        return int(self._lib.gip_streamer_launches(self._s))
 
     def close(self):
         if self._s:

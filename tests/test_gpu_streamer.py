@@ -22,8 +22,8 @@ def _processor(w, h, nd, block):
     return proc, calib
 
 
-@pytest.mark.parametrize("depth,fpb,nframes", [(3, 1, 7), (2, 2, 5), (4, 3, 10)])
-def test_streamed_outputs_equal_process_pair(gpu, depth, fpb, nframes):
+@pytest.mark.parametrize("depth,fpb,nframes,adaptive,lanes", [(3, 1, 7, False, 1), (2, 2, 5, False, 2), (4, 3, 10, False, 0), (0, 0, 12, True, 0), (3, 4, 11, True, 3), (2, 2, 9, True, 1)])
+def test_streamed_outputs_equal_process_pair(gpu, depth, fpb, nframes, adaptive, lanes):
     from ros_gpu_stereo_processor_amd import capi
     from ros_gpu_stereo_processor_amd import processor as P
     from ros_gpu_stereo_processor_amd.streamer import Streamer
@@ -47,12 +47,13 @@ def test_streamed_outputs_equal_process_pair(gpu, depth, fpb, nframes):
     def on_result(seq, header, d16, f32, cloud):
         order.append(seq)
         got[seq] = (header.seq, d16, f32, cloud)
-    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, want_disparity16=True, depth=depth, frames_per_batch=fpb, on_result=on_result)
+    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, want_disparity16=True, depth=depth, frames_per_batch=fpb, on_result=on_result, adaptive=adaptive, compute_lanes=lanes)
     for i, (l, r) in enumerate(frames):
         hdr = capi.Header(seq=1000 + i, stamp_sec=i, stamp_nsec=7, frame_id=b"cam")
         st.submit(l, r, hdr)
     st.flush()
     assert st.delivered() == nframes
+    assert 1 <= st.launches() <= nframes and (adaptive or st.launches() == -(-nframes // max(fpb, 1)))
     assert order == list(range(nframes))                       # delivery in submission order
     for i in range(nframes):
         hseq, d16, f32, cloud = got[i]
@@ -74,7 +75,7 @@ def test_streamer_counts_without_callback_and_rejects_bad_config(gpu):
     w, h, nd = 320, 96, 32
     proc, calib = _processor(w, h, nd, 7)
     l, r = synth.raw_pair(w, h, nd, seed=3, calib=calib)[:2]
-    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY, depth=3, frames_per_batch=4)
+    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY, depth=3, frames_per_batch=4, adaptive=False)
     for _ in range(9):
         st.submit(l, r)
     st.flush()
@@ -130,4 +131,45 @@ def test_streamed_bayer_colour_cloud_equals_process_pair(gpu):
         assert np.array_equal(got[i][0], exp[i][0]), i
         assert np.array_equal(got[i][1].view(np.uint8), exp[i][1].view(np.uint8)), i
     assert len(np.unique(exp[0][1][..., 16:19].reshape(-1, 3), axis=0)) > 50        # the cloud really carries colour
+    proc.close()
+
+
+def test_streamer_failed_launch_is_sticky_and_shapes_are_checked(gpu):
+    """A launch that gip_batch_run rejects (the block size is made larger than the image after open) must not leave a half-filled slot behind:
+    the streamer drains, reports the error from submit and flush from then on, and still closes cleanly (no write past a slot, no hang).
+    Images of the wrong shape never reach the C side."""
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.streamer import Streamer
+    w, h, nd = 320, 96, 32
+    proc, calib = _processor(w, h, nd, 7)
+    l, r = synth.raw_pair(w, h, nd, seed=3, calib=calib)[:2]
+    for adaptive, fpb in ((True, 0), (False, 2)):
+        proc.setBlockSize(7)
+        got = []
+        st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY, depth=2, frames_per_batch=fpb, adaptive=adaptive, compute_lanes=1, on_result=lambda *a: got.append(a[0]))
+        st.submit(l, r)
+        st.submit(l, r)
+        st.flush()
+        assert st.delivered() == 2
+        with pytest.raises(ValueError):
+            st.submit(l[:-1], r[:-1])
+        with pytest.raises(ValueError):
+            st.submit(np.stack([l] * 3, -1), np.stack([r] * 3, -1))
+        proc.setBlockSize(255)                  # valid for the setter, impossible for a 96-row image: StereoBM validation fails inside the launch
+        with pytest.raises(capi.GipError):
+            for _ in range(3):                  # fixed batching launches on the second pair
+                st.submit(l, r)
+        for _ in range(3):                      # sticky: the same error, nothing written anywhere
+            with pytest.raises(capi.GipError):
+                st.submit(l, r)
+        with pytest.raises(capi.GipError):
+            st.flush()
+        assert st.delivered() == 2
+        st.close()
+    proc.setBlockSize(7)
+    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY)      # a fresh streamer on the same processor works again
+    st.submit(l, r)
+    st.flush()
+    assert st.delivered() == 1
+    st.close()
     proc.close()
