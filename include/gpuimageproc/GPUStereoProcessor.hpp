@@ -143,6 +143,13 @@ class GpuStereoProcessor
         ck(gip_enqueue_send_disparity(h_, source, &imagePattern, pub ? &GpuStereoProcessor::disparity_tramp : nullptr, (void *)pub, &id));
         return std::make_shared<GPUSenderDisparity>(h_, id);
     }
+    // valid window, f, T, disparity range and delta_d of a DisparityImage of this processor (for maps that arrive through the streaming API)
+    gip_disparity_msg disparityInfo(int width, int height)
+    {
+        gip_disparity_msg m{};
+        ck(gip_disparity_info(h_, width, height, &m));
+        return m;
+    }
     GPUSenderPc2Ptr enqueueSendPoints(GpuMatSource points_source, GpuMatSource color_source, const gip_header &imagePattern, const PointCloud2Publisher *pub)
     {
         int id = -1;

@@ -223,6 +223,10 @@ int gip_project_disparity_to_3d_points(gip_handle h, int disparity_slot, int poi
 int gip_enqueue_send_image(gip_handle h, int slot, const gip_header *header, const char *encoding, gip_image_cb cb, void *user, int *sender_id);
 int gip_enqueue_send_disparity(gip_handle h, int slot, const gip_header *header, gip_disparity_cb cb, void *user, int *sender_id);
 int gip_enqueue_send_points(gip_handle h, int points_slot, int color_slot, const gip_header *header, gip_pointcloud2_cb cb, void *user, int *sender_id);
+/* valid_window, f, T, min / max disparity, delta_d of a stereo_msgs/DisparityImage for a width x height map of this processor -- what
+ * GPUSenderDisparity::fillInData derives (GpuSenderDisparity.cpp:29-43); header and image fields are left untouched.  For callers that
+ * receive the float map through gip_streamer_* instead of a sender. */
+int gip_disparity_info(gip_handle h, int width, int height, gip_disparity_msg *out);
 int gip_sender_was_sent(gip_handle h, int sender_id); /* GPUSenderIfc::wasDataSent */
 const gip_image_msg *gip_sender_image_msg(gip_handle h, int sender_id);
 const gip_disparity_msg *gip_sender_disparity_msg(gip_handle h, int sender_id);

@@ -142,6 +142,7 @@ PROTOTYPES = {
     "gip_enqueue_send_image": (_i, [_vp, _i, C.POINTER(Header), C.c_char_p, IMAGE_CB, _vp, C.POINTER(_i)]),
     "gip_enqueue_send_disparity": (_i, [_vp, _i, C.POINTER(Header), DISPARITY_CB, _vp, C.POINTER(_i)]),
     "gip_enqueue_send_points": (_i, [_vp, _i, _i, C.POINTER(Header), POINTCLOUD2_CB, _vp, C.POINTER(_i)]),
+    "gip_disparity_info": (_i, [_vp, _i, _i, C.POINTER(DisparityMsg)]),
     "gip_sender_was_sent": (_i, [_vp, _i]),
     "gip_sender_image_msg": (C.POINTER(ImageMsg), [_vp, _i]),
     "gip_sender_disparity_msg": (C.POINTER(DisparityMsg), [_vp, _i]),

@@ -934,24 +934,7 @@ int gip_enqueue_send_disparity(gip_handle h, int slot, const gip_header* header,
     m.image.step = (uint32_t)step;
     m.image.data = (uint8_t*)snd->host;
     m.image.data_size = step * f->rows;
-    // valid window / range / f / T as GPUSenderDisparity::fillInData computes them (GpuSenderDisparity.cpp:29-43), with
-    // the constructor arguments in their DECLARED order (minDisparity, fx, baseline); the reference call site passes
-    // (fx, baseline, minDisparity) into those positions (GPUStereoProcessor.cpp:221-222), which is a defect.
-    const int block = h->params.block_size, ndisp = h->params.num_disparities, mind = h->params.min_disparity;
-    const int border = block / 2;
-    const int left = ndisp + mind + border - 1;
-    const int wtf = (mind >= 0) ? border + mind : (border > -mind ? border : -mind);
-    const int right = (int)m.image.width - 1 - wtf;
-    const int top = border, bottom = (int)m.image.height - 1 - border;
-    m.valid_x_offset = left;
-    m.valid_y_offset = top;
-    m.valid_width = right - left;
-    m.valid_height = bottom - top;
-    m.min_disparity = (float)(mind + 1);
-    m.max_disparity = (float)(mind + ndisp - 1);
-    m.f = (float)h->model.right.fx();
-    m.T = (float)h->model.baseline();
-    m.delta_d = 1.0f / 16;  // never set by the reference; stereo_image_proc's value for a x16 fixed-point matcher
+    if ((rc = gip_disparity_info(h, f->cols, f->rows, &m)) != GIP_OK) return rc;
     snd->dcb = cb;
     snd->user = user;
     if ((rc = begin_read(h, f, st)) != GIP_OK) return rc;
@@ -961,6 +944,34 @@ int gip_enqueue_send_disparity(gip_handle h, int slot, const gip_header* header,
         H_HIP(h, hipMemcpy2DAsync(snd->host, step, f->d, f->pitch, step, f->rows, hipMemcpyDeviceToHost, st));
     if ((rc = end_read(h, f, st)) != GIP_OK) return rc;
     H_HIP(h, hipLaunchHostFunc(st, host_send_cb, snd));
+    return GIP_OK;
+}
+
+// the metadata of a stereo_msgs/DisparityImage for a width x height map computed with the handle's parameters and model
+int gip_disparity_info(gip_handle h, int width, int height, gip_disparity_msg* out)
+{
+    H_CHECK(h);
+    if (!out || width <= 0 || height <= 0) return fail(h, GIP_ERR_INVALID_ARG, "disparity_info: bad arguments");
+    if (!h->model.initialised) return fail(h, GIP_ERR_NOT_INITIALISED, "disparity_info: stereo model not initialised");
+    gip_disparity_msg& m = *out;
+    // valid window / range / f / T as GPUSenderDisparity::fillInData computes them (GpuSenderDisparity.cpp:29-43), with
+    // the constructor arguments in their DECLARED order (minDisparity, fx, baseline); the reference call site passes
+    // (fx, baseline, minDisparity) into those positions (GPUStereoProcessor.cpp:221-222), which is a defect.
+    const int block = h->params.block_size, ndisp = h->params.num_disparities, mind = h->params.min_disparity;
+    const int border = block / 2;
+    const int left = ndisp + mind + border - 1;
+    const int wtf = (mind >= 0) ? border + mind : (border > -mind ? border : -mind);
+    const int right = width - 1 - wtf;
+    const int top = border, bottom = height - 1 - border;
+    m.valid_x_offset = left;
+    m.valid_y_offset = top;
+    m.valid_width = right - left;
+    m.valid_height = bottom - top;
+    m.min_disparity = (float)(mind + 1);
+    m.max_disparity = (float)(mind + ndisp - 1);
+    m.f = (float)h->model.right.fx();
+    m.T = (float)h->model.baseline();
+    m.delta_d = 1.0f / 16;  // never set by the reference; stereo_image_proc's value for a x16 fixed-point matcher
     return GIP_OK;
 }
 

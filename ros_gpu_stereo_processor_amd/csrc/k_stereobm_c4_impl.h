@@ -38,6 +38,7 @@
 #include "bm_common.h"
 
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -49,16 +50,10 @@
 #ifndef C4_ABLATE
 #define C4_ABLATE 0
 #endif
-// measured design switches (tools/ab_c4.sh, tools/bm_ab.py)
-#ifndef C4_PIPE     /* 1: subtract the leaving row at the top of the NEXT iteration from registers read before finalisation */
-#define C4_PIPE 0
-#endif
-#ifndef C4_B128     /* 1: park two groups per 16-byte LDS store */
-#define C4_B128 1
-#endif
-#ifndef C4_OCT      /* 1: winner-take-all and uniqueness count per 8-disparity group (pairs of v_mqsad groups) when NG is even */
-#define C4_OCT 1
-#endif
+// measured design switches (tools/ab_c4.sh, tools/bm_ab.py).  The variants that lost their A/B and are gone from the source:
+// subtracting the leaving row at the top of the next iteration from registers read before finalisation (+4 % time), 8-byte parks (bank
+// conflicts: 68 M vs 14 M conflict cycles), 4-disparity winner-take-all groups for even NG (+14 M instructions), ds_bpermute quarter merges
+// (two LDS round trips per merge).
 #ifndef C4_ROTFIN   /* 1: multi-wave workgroups: ONE wave (rotating per row) finalises all 64 pixels of the row with every lane active */
 #define C4_ROTFIN 1
 #endif
@@ -71,6 +66,8 @@
 #ifndef C4_NOSYNC   /* 1: one-wave workgroups order their LDS traffic by program order only (no s_waitcnt drain) */
 #define C4_NOSYNC 1
 #endif
+
+constexpr int GIP_MAX_DEVICES = 64;
 
 namespace {
 
@@ -110,9 +107,6 @@ struct P2 { u32 lo, hi; };
 __device__ __forceinline__ P2 operator+(P2 a, P2 b) { return {a.lo + b.lo, a.hi + b.hi}; }
 __device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi - b.hi}; }
 
-#ifndef C4_SWAPRED
-#define C4_SWAPRED 1    // 1: quarter merges by v_permlane16_swap / v_permlane32_swap (VALU only); 0: two ds_bpermute round trips
-#endif
 // Reduction of a value over the four lanes t, t+16, t+32, t+48 (the disparity quarters of one column group), result in all four, for a
 // commutative, associative op.  gfx950 has two VALU lane-swap instructions for exactly this (measured: tools/probe/permlane_swap_probe.hip):
 // v_permlane16_swap a, b exchanges the ODD 16-lane rows of a with the EVEN rows of b, v_permlane32_swap the upper half of a with the lower
@@ -121,15 +115,10 @@ __device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi 
 template <typename Op>
 __device__ __forceinline__ u32 quarters_reduce(u32 x, Op op)
 {
-#if C4_SWAPRED
     auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
     x = op((u32)r[0], (u32)r[1]);
     auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return op((u32)h[0], (u32)h[1]);
-#else
-    x = op(x, (u32)__shfl_xor((int)x, 16));
-    return op(x, (u32)__shfl_xor((int)x, 32));
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -351,7 +340,6 @@ template <int NG, int R, int NW, bool PF, bool RF>
 __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb, int img)
 {
     constexpr int NRING = RF ? 2 : 2 * R + 1;   // RF: slot 0 = the entering row, slot 1 = the leaving row
-    static_assert(!(RF && C4_PIPE), "the early-subtract variant reads the ring");
     constexpr int NS = 4 * NW;                  // disparity slices
     constexpr int NT = 64 * NW;                 // threads
     constexpr int NDISP = 4 * NG * NS;
@@ -365,7 +353,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     // at finalisation.  With 8-disparity groups ("octets" = two v_mqsad groups, which are parked together anyway) the per-group work --
     // horizontal min, key, running min, uniqueness compare-and-count -- halves; finalisation reads three octets instead of three quads.
     // NG must be even so that no octet is split between two lanes (the count would see it twice).
-    constexpr bool OCT = (C4_OCT != 0) && (C4_B128 != 0) && (NG % 2 == 0);
+    constexpr bool OCT = NG % 2 == 0;
     constexpr int NGK = OCT ? NG / 2 : NG;      // key groups per lane
     u32* ring = (u32*)smem_raw;
     uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
@@ -573,20 +561,16 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     });
     const uint8_t* csrow_r = live_lane ? cs + (size_t)(qf * NLIVE + t - TLO) * CSPB : dump;
 
-    // Software pipeline of one iteration (row y):
-    //   commit row y+R to the ring -> issue its LDS reads (A) and the global loads of row y+R+1 -> SUBTRACT row y-R-1, whose
-    //   registers (S) were read during the previous iteration -> add row y+R -> window sums / WTA -> issue the LDS reads of row
-    //   y-R (the next S; its slot is not overwritten before the next commit) -> merge, uniqueness, finalise, store.
-    RowRegs S = {};
+    // One iteration (row y): commit row y+R to the ring -> issue its LDS reads (A) and the global loads of row y+R+1 -> add row y+R ->
+    // window sums / WTA / parks -> merge, uniqueness, finalise, store -> subtract row y-R (the row that leaves the window).
     for (int y = ya; y < yb; y++) {
-        wg_sync();                // every wave is done with the slot row y+R replaces (its reads are in S)
+        wg_sync();                // every wave is done with the slot row y+R replaces
         commit(y + R);
         if constexpr (RF) commit_to(pfS, 1);        // row y-R
         wg_sync();
         const RowRegs A = RF ? read_slot(0) : read_row(y + R);
         if (y + R + 1 < a.h) prefetch(y + R + 1);
         if constexpr (RF) prefetch_to(pfS, y - R + 1);
-        if (C4_PIPE && y > ya && !(C4_ABLATE & 1)) sub_regs(S);
         add_regs(A);
 
         // ---- horizontal window sums, group keys, cost slice
@@ -637,7 +621,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         };
 #pragma unroll
         for (int g = 0; g < NG; g += 2) {
-            const bool two = C4_B128 && g + 1 < NG;
+            const bool two = g + 1 < NG;
             P2 Ha[4], Hb[4] = {};
             window_sums(g, Ha);
             if (two) window_sums(g + 1, Hb);
@@ -650,7 +634,6 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 }
                 park(qv, g, Ha[q], Hb[q], two);
             });
-            if (!C4_B128) g--;    // one group per step
         }
         if constexpr (PF) {
             hsum_pf<R>(TV[3], TV[0], TV[1], TV[2], tsum_q[0], tsum_q[1], tsum_q[2], tsum_q[3]);
@@ -661,8 +644,6 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             auto shift = [](auto dv, u32 v) -> u32 { return lane_at<decltype(dv)::value>(v); };
             static_for<0, 4>([&](auto qv) { constexpr int q = decltype(qv)::value; tsum_q[q] = hsum<R, q>(P, shift); });
         }
-        // the row that leaves the window next: issue its LDS reads now, they are consumed at the top of the next iteration
-        if constexpr (C4_PIPE != 0) { if (y + 1 < yb) S = read_row(y - R); }
         // merge the four disparity quarters (lanes t, t+16, t+32, t+48)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -804,7 +785,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
             }
         }
         }   // finalising wave
-        if (!C4_PIPE && !(C4_ABLATE & 1)) sub_regs(RF ? read_slot(1) : read_row(y - R));
+        if (!(C4_ABLATE & 1)) sub_regs(RF ? read_slot(1) : read_row(y - R));
     }
 }
 
@@ -848,8 +829,15 @@ __global__ void __launch_bounds__(64 * NW, C4_MINW) k_bm_c4(BmArgs a)
 template <int NG, int R, int NW, bool RF>
 int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
-    // measurement knob: GIP_C4_LDS_PAD=n allocates n more bytes of LDS per workgroup (fewer matcher workgroups per CU; read once)
+    // measurement knobs (tools/chunk_sweep.sh; compiled in only with -DC4_MEASURE_KNOBS, never in the product build -- a stray environment
+    // variable must not change occupancy or chunking in production): GIP_C4_LDS_PAD=n allocates n more bytes of LDS per workgroup,
+    // GIP_C4_CHUNKS=n forces the chunk count; both read once
+#ifdef C4_MEASURE_KNOBS
     static const int env_pad = [] { const char* e = getenv("GIP_C4_LDS_PAD"); return e ? atoi(e) : 0; }();
+    static const int env_chunks = [] { const char* e = getenv("GIP_C4_CHUNKS"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int env_pad = 0, env_chunks = 0;
+#endif
     size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1) + (size_t)(env_pad > 0 ? env_pad : 0);
     const int ncols = a.cend - a.cbeg;
     const int ntiles = (ncols + (64 - 2 * R) - 1) / (64 - 2 * R);
@@ -860,23 +848,28 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
     // no winner-take-all), and the workgroups do not all take the same time (border tiles run the slower column form), which costs
     // about half a workgroup's duration at the end whatever the fill.  The constants are fitted to forced-chunk sweeps of seven shapes
     // (tools/chunk_sweep.sh, profiles/r02_chunk_sweep.txt): the pick is within 2 % of the best forced count on each.
-    static int n_cu = 0;
+    // per DEVICE (a process may own several: MultiDeviceStereo, gip_rowsplit_*), filled once each; racing first calls write the same value
+    static std::atomic<int> n_cu_of[GIP_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GIP_MAX_DEVICES) dev = 0;
+    int n_cu = n_cu_of[dev].load(std::memory_order_relaxed);
     if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
-        else n_cu = 256;
+        int v = 0;
+        n_cu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        n_cu_of[dev].store(n_cu, std::memory_order_relaxed);
     }
     int per_cu = c4_per_cu(sh, NW);
     // ... and no more waves per SIMD than the kernel's register count leaves room for (512 VGPRs per lane and SIMD, allocated in blocks of 8)
-    static int vgpr_waves = 0;      // one static per instantiation
-    if (vgpr_waves == 0) {
+    // (the register count is a property of the code object, the same on every gfx950 device: one value per instantiation)
+    static std::atomic<int> vgpr_alloc_c{0};
+    int vgpr_alloc = vgpr_alloc_c.load(std::memory_order_relaxed);
+    if (vgpr_alloc == 0) {
         hipFuncAttributes fa;
-        vgpr_waves = 8;
-        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW, RF>) == hipSuccess && fa.numRegs > 0) {
-            const int regs = (fa.numRegs + 7) & ~7;
-            vgpr_waves = 512 / regs < 1 ? 1 : (512 / regs > 8 ? 8 : 512 / regs);
-        }
+        vgpr_alloc = 128;
+        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW, RF>) == hipSuccess && fa.numRegs > 0) vgpr_alloc = (fa.numRegs + 7) & ~7;
+        vgpr_alloc_c.store(vgpr_alloc, std::memory_order_relaxed);
     }
+    const int vgpr_waves = 512 / vgpr_alloc < 1 ? 1 : (512 / vgpr_alloc > 8 ? 8 : 512 / vgpr_alloc);
     if (per_cu > 4 * vgpr_waves / NW) per_cu = 4 * vgpr_waves / NW;
     if (per_cu < 1) per_cu = 1;
     // Co-scheduled (other batches' kernels run next to this launch): a matcher that fills every SIMD's register file (4 waves x 128 VGPRs at
@@ -885,12 +878,6 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
     // -10 %, pipeline -3.4 %; capped: pipeline +1.3 %).  So: never more than 90 % of the CU's registers, by padding the LDS request just far
     // enough that one workgroup less fits (the rest of the LDS stays free for the other kernels).  Shapes below that line are left alone:
     // a stricter rule (always leave 128 registers per SIMD) cost nd 192 / block 15 11 % and nd 48 / block 19 7 % (tools/bench_ab.sh).
-    static int vgpr_alloc = 0;
-    if (vgpr_alloc == 0) {
-        hipFuncAttributes fa;
-        vgpr_alloc = 128;
-        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW, RF>) == hipSuccess && fa.numRegs > 0) vgpr_alloc = (fa.numRegs + 7) & ~7;
-    }
     if (ctx && ctx->co_scheduled) {
         int cap = per_cu;
         while (cap > 1 && cap * NW * vgpr_alloc * 10 > 4 * 512 * 9) cap--;
@@ -904,8 +891,6 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
 #ifdef C4_FIXED_CHUNKS
     int nch = C4_FIXED_CHUNKS;
 #else
-    // measurement knob (tools/chunk_sweep.sh): GIP_C4_CHUNKS=n forces the chunk count; read once
-    static const int env_chunks = [] { const char* e = getenv("GIP_C4_CHUNKS"); return e ? atoi(e) : 0; }();
     const double capacity = (double)n_cu * per_cu;
     int nch = 1;
     double best_cost = 1e300;

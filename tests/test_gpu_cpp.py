@@ -1,5 +1,6 @@
-"""GPU test (-m gpu): the C++ mirror classes (include/gpuimageproc/*.hpp) compiled against libgpuimageproc_hip.so and driven
-like the reference's nodelet (configCb + imageCb); outputs are checked against the CPU oracle."""
+"""GPU test (-m gpu): the C++ mirror classes (include/gpuimageproc/*.hpp) built through the CMake package (library configured, built and
+installed by the top-level CMakeLists.txt; the test as a downstream find_package consumer) and driven like the reference's nodelet
+(configCb + imageCb, the streaming classes, the row split); outputs are checked against the CPU oracle."""
 import os
 import shutil
 import subprocess
@@ -12,15 +13,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_cpp_mirror_classes(gpu, oracle, kitchen, calib, calib_files, tmp_path):
-    from ros_gpu_stereo_processor_amd import capi
-    libdir = os.path.dirname(capi.LIB_PATH)
-    exe = tmp_path / "test_processor"
-    cxx = shutil.which("hipcc") or shutil.which("g++")
-    cmd = [cxx, "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_processor.cpp"), "-L", libdir,
-           "-lgpuimageproc_hip", "-Wl,-rpath," + libdir, "-o", str(exe)]
-    if "hipcc" not in cxx:
-        cmd += ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
-    subprocess.check_call(cmd)
+    # the CMake package end to end: configure + build + install the library (top-level CMakeLists.txt), then build the test as a DOWNSTREAM
+    # project that only knows find_package(gpuimageproc_hip) (tests/cpp/consumer) -- the way a catkin / CMake user consumes it
+    cmake = shutil.which("cmake")
+    assert cmake, "cmake not found"
+    build, prefix, cbuild = tmp_path / "build", tmp_path / "prefix", tmp_path / "consumer_build"
+    jobs = str(min(16, os.cpu_count() or 4))
+
+    def run(*cmd):
+        out = subprocess.run(list(cmd), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, " ".join(cmd) + "\n" + out.stdout[-3000:] + out.stderr[-3000:]
+    run(cmake, "-S", ROOT, "-B", str(build), "-DCMAKE_PREFIX_PATH=/opt/rocm", "-DGIP_BUILD_ROS=OFF", "-DGIP_BUILD_TESTS=OFF")
+    run(cmake, "--build", str(build), "-j", jobs)
+    run(cmake, "--install", str(build), "--prefix", str(prefix))
+    assert (prefix / "lib" / "cmake" / "gpuimageproc_hip" / "gpuimageproc_hipConfig.cmake").exists() and (prefix / "include" / "gpuimageproc_hip.h").exists()
+    run(cmake, "-S", os.path.join(ROOT, "tests", "cpp", "consumer"), "-B", str(cbuild), "-DCMAKE_PREFIX_PATH=%s;/opt/rocm" % prefix)
+    run(cmake, "--build", str(cbuild), "-j", jobs)
+    exe = cbuild / "test_processor"
     kitchen["left_raw"].tofile(tmp_path / "left_raw.bin")
     kitchen["right_raw"].tofile(tmp_path / "right_raw.bin")
     shutil.copy(calib_files[0], tmp_path / "left.yaml")

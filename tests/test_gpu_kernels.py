@@ -457,3 +457,53 @@ def test_bm_result_independent_of_row_chunking(gpu, oracle):
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.strip().splitlines()[-1] == want, chunks
+
+
+@pytest.mark.parametrize("uniq,block,cap", [(199, 21, 63), (200, 21, 63), (15, 21, 63), (199, 9, 31), (200, 9, 31), (150, 23, 63)])
+def test_bm_extreme_uniqueness_and_cost_range(gpu, oracle, uniq, block, cap):
+    """The corners of the column-sum matcher's integer shortcuts: uniqueness ratio 199 (the last value its multiply-shift threshold
+    (ms * K) >> 23 is exact for, on the device's 24-bit multiplies) against 200 (falls back to the generic kernels), and prefilter cap 63 with
+    block 21, where a window sum reaches 2 * 63 * 441 = 55 566 of the 65 535 a uint16 holds and the sub-pixel numerator |p - n| * 256
+    approaches 2^24 (block 23 at cap 63 no longer fits and takes the 32-bit kernel).  Inputs are PREFILTERED planes built to hit those
+    ranges: binary {0, 2 cap} texture with planted shifts (winner cost 0, neighbours about half the maximum), a band where left and right
+    differ by 2 cap everywhere (every cost at the maximum: ties, threshold = ms + ms * uniq / 100 far above 16 bits), and noise."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    w, h, nd = 420, 132, 64
+    rng = np.random.default_rng(1000 * uniq + block)
+    hi = 2 * cap
+    base = (rng.integers(0, 2, (h, w + nd)) * hi).astype(np.uint8)
+    rf = base[:, nd:].copy()                       # right(x) = base(x + nd)
+    lf = np.empty_like(rf)
+    for y0 in range(0, h, 44):                     # left(x) = right(x - d) = base(x + nd - d): a different planted shift every 44 rows (> the block)
+        d = int(rng.integers(2, nd - 2))
+        lf[y0:y0 + 44] = base[y0:y0 + 44, nd - d:nd - d + w]
+    flip = rng.random((h, w)) < 0.03
+    lf[flip] = hi - lf[flip]
+    lf[44:88, 100:260] = 0                         # every cost of the windows inside this patch is the maximum
+    rf[44:88, :] = hi
+    lf[120:130] = rng.integers(0, hi + 1, (10, w)).astype(np.uint8)
+    for tex, d12, u in ((0, 1, uniq), (10, -1, uniq), (0, 1, 0)):      # uniqueness 0: the all-maximum windows stay valid (largest costs the plane can carry)
+        kw = dict(prefilter_cap=cap, block_size=block, num_disparities=nd, min_disparity=0, texture_threshold=tex, uniqueness_ratio=u, disp12_max_diff=d12)
+        exp_d, exp_c = oracle.bm_match(lf, rf, oracle.bm_params(**kw))
+        got_d, got_c = K.bm_match(_t(lf, gpu), _t(rf, gpu), K.bm_params(**kw))
+        got_d, got_c = _n(got_d), _n(got_c)
+        if d12 < 0:
+            roi = oracle.valid_disparity_roi(w, h, oracle.bm_params(**kw))
+            sl = (slice(roi[1], roi[1] + roi[3]), slice(roi[0], roi[0] + roi[2]))
+            assert np.array_equal(got_d[sl], exp_d[sl])
+        else:
+            assert np.array_equal(got_d, exp_d)
+            valid = exp_d != -16
+            assert np.array_equal(got_c[valid], exp_c[valid])
+            assert valid.mean() > 0.05 and (u > 0 or exp_c[valid].max() == 2 * cap * block * block)
+    # and through cv::StereoBM::compute with the XSOBEL prefilter at that cap, on raw noise with planted shifts
+    raw_b = rng.integers(0, 256, (h, w + nd)).astype(np.uint8)
+    rr = raw_b[:, nd:].copy()
+    rl = np.empty_like(rr)
+    for y0 in range(0, h, 44):
+        d = int(rng.integers(2, nd - 2))
+        rl[y0:y0 + 44] = raw_b[y0:y0 + 44, nd - d:nd - d + w]
+    kw = dict(prefilter_type=1, prefilter_cap=cap, block_size=block, num_disparities=nd, min_disparity=0, texture_threshold=10, uniqueness_ratio=uniq, disp12_max_diff=1)
+    exp = oracle.stereobm(rl, rr, oracle.bm_params(**kw))
+    got = _n(K.stereobm(_t(rl, gpu), _t(rr, gpu), K.bm_params(**kw)))
+    assert np.array_equal(got, exp) and (exp != -16).mean() > 0.05

@@ -27,8 +27,10 @@ hd1080|uhd4k|euroc|refdefault)
   pmc r02_${what}_pmc_sq1_k_bm_c4 k_bm_c4 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -- --workload $what ;;
 calib)
   rm -rf /tmp/q_cal_f /tmp/q_cal_w
-  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/q_cal_f -o r -- $R/tools/probe/fetch_calib > /dev/null 2>&1
-  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/q_cal_w -o r -- $R/tools/probe/fetch_calib > /dev/null 2>&1
+  # the probe is built from its source where it runs (never a checked-in binary), and is the program right after `--`
+  hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_calib $R/tools/probe/fetch_calib.hip || exit 1
+  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/q_cal_f -o r -- /tmp/fetch_calib > /dev/null 2>&1
+  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/q_cal_w -o r -- /tmp/fetch_calib > /dev/null 2>&1
   { echo "# 1 GiB streamed in and out per kernel (1048576 KB): FETCH_SIZE / WRITE_SIZE in KB by access width per lane"; python3 $R/tools/pmc_summary.py $(find /tmp/q_cal_f -name "*counter_collection.csv" | head -1) k_copy;
     python3 $R/tools/pmc_summary.py $(find /tmp/q_cal_w -name "*counter_collection.csv" | head -1) k_copy; } > $O/r02_pmc_calibration.txt ;;
 esac
