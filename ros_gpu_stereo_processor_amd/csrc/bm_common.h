@@ -22,6 +22,7 @@ struct BmArgs {
     size_t img_bs, disp_bs, cost_bs;  // batch strides in bytes
     int filtered;
     int ntiles, nchunks, nimg;   // column-sum matcher: extent of its (tile, row chunk, image) work space (set by the launcher)
+    int batch;                   // column-sum matcher: images in the batch (nimg = batch, or ceil(batch / 2) when a wave takes two images)
 };
 
 // Host-side launch context of the dominant kernel (the SAD matcher); every field may be null.  Travels as an argument from

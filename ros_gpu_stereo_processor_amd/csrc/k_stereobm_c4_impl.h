@@ -112,13 +112,17 @@ __device__ __forceinline__ P2 operator-(P2 a, P2 b) { return {a.lo - b.lo, a.hi 
 // v_permlane16_swap a, b exchanges the ODD 16-lane rows of a with the EVEN rows of b, v_permlane32_swap the upper half of a with the lower
 // half of b.  With a = b = x:  a' = {x.r0, x.r0, x.r2, x.r2}, b' = {x.r1, x.r1, x.r3, x.r3}, so op(a', b') is the xor-16 butterfly step in every
 // lane, and the same with halves for xor-32 -- no LDS round trip (ds_bpermute: the wave parks ~100+ cycles per dependent step).
-template <typename Op>
+// NSL = 4: over all four rows; NSL = 2 (two sub-images per wave, each in one 32-lane half): over the two rows of each half only.
+template <int NSL = 4, typename Op>
 __device__ __forceinline__ u32 quarters_reduce(u32 x, Op op)
 {
     auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
     x = op((u32)r[0], (u32)r[1]);
-    auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return op((u32)h[0], (u32)h[1]);
+    if constexpr (NSL == 4) {
+        auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        x = op((u32)h[0], (u32)h[1]);
+    }
+    return x;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -297,12 +301,12 @@ constexpr int c4_dump_off(int q, int t, int R, int cspb)
         }
     return 0;
 }
-constexpr size_t c4_lds_bytes(int NG, int R, int NW, int nring)
+constexpr size_t c4_lds_bytes(int NG, int R, int NW, int nring, int NSUB = 1)
 {
-    const int NS = 4 * NW, RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
-    // ring + cost slice + (multi-wave workgroups only) the exchange area for winner keys and uniqueness counts
+    const int NS = (4 / NSUB) * NW, RWD = 17 + NS * NG, RWDP = (RWD + 3) & ~3, SLOTD = 16 + RWDP;
+    // ring + cost slice (one of each per sub-image) + (multi-wave workgroups only) the exchange area for winner keys and uniqueness counts
     const int cspb = 2 * 4 * NG * NS + 16;
-    return (size_t)nring * SLOTD * 4 + (size_t)c4_slice_rows(R) * cspb + (R / 4 > 0 ? c4_dump_bytes(cspb) : 0) + (NW > 1 ? (size_t)2 * NW * 64 * 4 : 0);
+    return (size_t)NSUB * ((size_t)nring * SLOTD * 4 + (size_t)c4_slice_rows(R) * cspb + (R / 4 > 0 ? c4_dump_bytes(cspb) : 0)) + (NW > 1 ? (size_t)2 * NW * 64 * 4 : 0);
 }
 constexpr int c4_per_cu(size_t lds, int NW)
 {
@@ -320,11 +324,11 @@ constexpr int c4_per_cu(size_t lds, int NW)
 #ifndef C4_REFETCH
 #define C4_REFETCH 1
 #endif
-constexpr bool c4_refetch(int NG, int R, int NW)
+constexpr bool c4_refetch(int NG, int R, int NW, int NSUB = 1)
 {
     // what the registers allow anyway (measured VGPR counts: NG <= 4 about 100-128 = 4 waves per SIMD, NG 5..7 up to 168 = 3, NG >= 8 more = 2)
     const int cap = NG <= 4 ? 16 : NG <= 7 ? 12 : 8;
-    const int with = c4_per_cu(c4_lds_bytes(NG, R, NW, 2), NW), without = c4_per_cu(c4_lds_bytes(NG, R, NW, 2 * R + 1), NW);
+    const int with = c4_per_cu(c4_lds_bytes(NG, R, NW, 2, NSUB), NW), without = c4_per_cu(c4_lds_bytes(NG, R, NW, 2 * R + 1, NSUB), NW);
     // NG > 12 (nd 208 / 240) holds all 256 VGPRs: register-bound whatever the LDS says (measured: +6 % with the refetch)
     return C4_REFETCH == 2 || (C4_REFETCH == 1 && NW == 1 && NG <= 12 && (with < cap ? with : cap) > (without < cap ? without : cap));
 }
@@ -336,18 +340,29 @@ constexpr bool c4_refetch(int NG, int R, int NW)
 // through LDS, the texture sums are computed by every wave, and a wave finalises only 64 / NW pixels per row.
 //
 // PF: prefix form (interior tile) or column form (border tile); uniform per workgroup.
-template <int NG, int R, int NW, bool PF, bool RF>
+//
+// NSUB = 2 (small disparity counts, one-wave workgroups): the wave works on the same tile and row chunk of TWO images of the batch, one per
+// 32-lane half; each half splits the disparity range over its two 16-lane rows only (NSL = 2 slices of NG groups, NG = ndisp / 8).  At
+// ndisp <= 64 the work a lane does per row is dominated by what does not shrink with the disparity count -- staging, texture sums, the
+// quarter merges, the uniqueness thresholds, one finalisation per lane: 11.4 lane-instructions per (pixel, disparity) at (48, 19) against
+// 5.1 at (128, 9).  With two slices per image every one of those is paid for twice the disparities, the merges lose a step, and NG is even
+// for every multiple of 16, so the 8-disparity winner-take-all groups apply to ndisp 16 and 48 too.  A lane finalises two pixels.  `img` is
+// then the index of the image PAIR; the second half of the last pair of an odd batch works on a copy of the first and stores nothing.
+template <int NG, int R, int NW, bool PF, bool RF, int NSUB = 1>
 __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, int c0, int ya, int yb, int img)
 {
+    static_assert(NSUB == 1 || (NSUB == 2 && NW == 1), "two sub-images per wave: one-wave workgroups only");
     constexpr int NRING = RF ? 2 : 2 * R + 1;   // RF: slot 0 = the entering row, slot 1 = the leaving row
-    constexpr int NS = 4 * NW;                  // disparity slices
+    constexpr int NSL = 4 / NSUB;               // disparity slices per wave (and sub-image)
+    constexpr int NS = NSL * NW;                // disparity slices
     constexpr int NT = 64 * NW;                 // threads
+    constexpr int NTS = NT / NSUB;              // threads that stage one sub-image's rows
     constexpr int NDISP = 4 * NG * NS;
     constexpr int RWD = 17 + NS * NG;           // right-row dwords needed per ring slot
     constexpr int RWDP = (RWD + 3) & ~3;        // padded to 16 bytes
     constexpr int SLOTD = 16 + RWDP;            // dwords per ring slot
     constexpr int CSPB = 2 * NDISP + 16;        // bytes per column of the cost slice
-    constexpr int NLD = (RWD + NT - 1) / NT;    // right-row dwords each thread stages per row
+    constexpr int NLD = (RWD + NTS - 1) / NTS;  // right-row dwords each thread stages per row
     constexpr int QPW = 4 / NW;                 // pixel columns q finalised per wave
     // Winner-take-all granularity: the key of a column is (min cost << 8 | group), the group's costs are re-read from the LDS cost slice
     // at finalisation.  With 8-disparity groups ("octets" = two v_mqsad groups, which are parked together anyway) the per-group work --
@@ -355,26 +370,34 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     // NG must be even so that no octet is split between two lanes (the count would see it twice).
     constexpr bool OCT = NG % 2 == 0;
     constexpr int NGK = OCT ? NG / 2 : NG;      // key groups per lane
-    u32* ring = (u32*)smem_raw;
-    uint8_t* cs = smem_raw + (size_t)NRING * SLOTD * 4;
+    constexpr int SLICE_BYTES = c4_slice_rows(R) * CSPB + (R / 4 > 0 ? c4_dump_bytes(CSPB) : 0);
+
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int lane = tid & 63, t = lane & 15;
+    const int sub = NSUB == 2 ? (lane >> 5) : 0;                 // sub-image of this lane
+    const int sl = NSUB == 2 ? ((lane >> 4) & 1) : (lane >> 4);  // disparity slice inside the wave (and sub-image)
+    const int s = NSL * wave + sl;
+    const int ti = NSUB == 2 ? (tid & 31) : tid;                 // index among the threads that stage this sub-image
+
+    u32* ring = (u32*)smem_raw + sub * SLOTD;                     // slot k of this sub-image: ring + k * NSUB * SLOTD
+    uint8_t* cs = smem_raw + (size_t)NRING * NSUB * SLOTD * 4 + (size_t)sub * SLICE_BYTES;
     u32* xbest = (u32*)(cs + (size_t)c4_slice_rows(R) * CSPB + (R / 4 > 0 ? c4_dump_bytes(CSPB) : 0));   // [NW][16][4] winner keys of each wave (NW > 1 only)
     u32* xcnt = xbest + NW * 64;                    // [NW][16][4] uniqueness counts of each wave
 
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const int lane = tid & 63, t = lane & 15, sl = lane >> 4, s = 4 * wave + sl;
-
-    const uint8_t* Lb = a.L + (size_t)img * a.img_bs;
-    const uint8_t* Rb = a.R + (size_t)img * a.img_bs;
-    int16_t* disp = (int16_t*)((uint8_t*)a.disp + (size_t)img * a.disp_bs);
-    int32_t* cost = a.cost ? (int32_t*)((uint8_t*)a.cost + (size_t)img * a.cost_bs) : nullptr;
+    const bool sub_live = img * NSUB + sub < a.batch;             // (odd batch: the last pair has one image)
+    const int im = sub_live ? img * NSUB + sub : a.batch - 1;
+    const uint8_t* Lb = a.L + (size_t)im * a.img_bs;
+    const uint8_t* Rb = a.R + (size_t)im * a.img_bs;
+    int16_t* disp = (int16_t*)((uint8_t*)a.disp + (size_t)im * a.disp_bs);
+    int32_t* cost = a.cost ? (int32_t*)((uint8_t*)a.cost + (size_t)im * a.cost_bs) : nullptr;
 
     // ---- row staging: aligned dword loads + funnel shift, clamped to the row's dword range (pitch % 4 == 0)
     const int lcol0 = a.lofs + c0;   // absolute column of L ring byte 0
     const int rcol0 = a.rofs + c0;   // absolute column of R ring byte 0
     const int ndw = (int)(a.pitch >> 2);
     const int lsh = lcol0 & 3, rsh = rcol0 & 3;
-    const int ldw = (lcol0 >> 2) + tid;  // (arithmetic shift: floor for negative columns)
-    const int rdw = (rcol0 >> 2) + tid;
+    const int ldw = (lcol0 >> 2) + ti;   // (arithmetic shift: floor for negative columns)
+    const int rdw = (rcol0 >> 2) + ti;
     auto fetch = [&](const uint8_t* base, int yy, int dw, int sh) -> u32 {
         const u32* row = (const u32*)(base + (size_t)yy * a.pitch);
         u32 lo = row[clampi(dw, 0, ndw - 1)], hi = row[clampi(dw + 1, 0, ndw - 1)];
@@ -384,7 +407,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     // left image, byte-granular edge replication (clamped-column rule: left column = clamp(lofs + cc, 0, w - 1)); only the
     // lanes whose quad straddles an image edge take the slow path
     auto fetch_l = [&](int yy) -> u32 {
-        const int col = lcol0 + 4 * tid;
+        const int col = lcol0 + 4 * ti;
         if (col >= 0 && col + 3 <= a.w - 1) return fetch(Lb, yy, ldw, lsh);
         const uint8_t* row = Lb + (size_t)yy * a.pitch;
         u32 v = 0;
@@ -408,17 +431,17 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     struct PfRegs { u32 l; u32 r[NLD]; };
     PfRegs pfE = {}, pfS = {};        // the row entering the window next; (RF) the row leaving it next
     auto prefetch_to = [&](PfRegs& pf, int yy) {
-        if (tid < 16) pf.l = fetch_l(yy);
+        if (ti < 16) pf.l = fetch_l(yy);
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (tid + NT * i < RWD) pf.r[i] = fetch(Rb, yy, rdw + NT * i, rsh);
+            if (ti + NTS * i < RWD) pf.r[i] = fetch(Rb, yy, rdw + NTS * i, rsh);
     };
     auto commit_to = [&](const PfRegs& pf, int sidx) {
-        u32* slot = ring + sidx * SLOTD;
-        if (tid < 16) slot[tid] = pf.l;
+        u32* slot = ring + sidx * NSUB * SLOTD;
+        if (ti < 16) slot[ti] = pf.l;
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (tid + NT * i < RWD) slot[16 + tid + NT * i] = pf.r[i];
+            if (ti + NTS * i < RWD) slot[16 + ti + NTS * i] = pf.r[i];
     };
     auto prefetch = [&](int yy) { prefetch_to(pfE, yy); };
     auto commit = [&](int yy) { commit_to(pfE, RF ? 0 : yy % NRING); };
@@ -444,7 +467,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     // two waves per SIMD an exposed LDS round trip is idle VALU time (SQ_WAIT_ANY, profiles/).
     struct RowRegs { u32 lw; u32 rd[NG + 1]; };
     auto read_slot = [&](int sidx) -> RowRegs {
-        const u32* slot = ring + sidx * SLOTD;
+        const u32* slot = ring + sidx * NSUB * SLOTD;
         RowRegs r;
         r.lw = slot[t];
         const u32* rw = slot + 16 + tw + NG * s;
@@ -535,13 +558,10 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
     // extra barrier, the same critical path, but three quarters of the finalisation's issue slots are left to other workgroups
     // (without ROT wave w takes q in [w*QPW, (w+1)*QPW) and its lanes with lane / 16 >= QPW idle through the whole block).
     constexpr bool ROT = (C4_ROTFIN != 0) && NW > 1;
-    const bool fin = ROT ? true : (sl < QPW);
-    const int qf = ROT ? sl : ((wave * QPW + sl) & 3);
-    const int my_col = 4 * t + qf;
-    const int c_out = c0 + my_col;
-    // a column is valid when its whole window lies inside the tile's 64 columns (column granularity, not lane granularity: for a radius that
-    // is not a multiple of 4 the outermost live lanes still produce 4 - R % 4 ... valid columns each)
-    const bool writer = fin && (my_col >= R) && (my_col <= 63 - R) && (c_out >= a.cbeg) && (c_out < a.cend);
+    // Two sub-images per wave (NSUB = 2): the two lanes that share a column quad finalise two pixels each, columns 4t + 2 sl + {0, 1}.
+    constexpr int NFIN = NSUB;                  // pixels a lane finalises per row
+    const bool fin = NSUB == 2 ? true : (ROT ? true : (sl < QPW));
+    const int qf0 = NSUB == 2 ? 2 * sl : (ROT ? sl : ((wave * QPW + sl) & 3));
     // cost slice rows ordered [q][live lane] (row = NLIVE q + t - TLO): the stores of consecutive lanes are CSPB = 4 (mod 32) dwords apart
     // (bank-conflict free).  The TLO lanes at either end of the row, which hold no output column, park all four of their columns in one
     // dump row each (never read): 6 TLO rows less LDS per workgroup -- at the metric's shape what lets a 10 KB workgroup of another
@@ -559,7 +579,6 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         });
         csw[q] = (live_lane ? cs + (size_t)(q * NLIVE + t - TLO) * CSPB : dump + 4 * doff) + (size_t)(4 * NG * s) * 2;
     });
-    const uint8_t* csrow_r = live_lane ? cs + (size_t)(qf * NLIVE + t - TLO) * CSPB : dump;
 
     // One iteration (row y): commit row y+R to the ring -> issue its LDS reads (A) and the global loads of row y+R+1 -> add row y+R ->
     // window sums / WTA / parks -> merge, uniqueness, finalise, store -> subtract row y-R (the row that leaves the window).
@@ -648,7 +667,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if constexpr (C4_ABLATE & 8) break;
-            best[q] = quarters_reduce(best[q], [](u32 x, u32 y) { return umin(x, y); });
+            best[q] = quarters_reduce<NSL>(best[q], [](u32 x, u32 y) { return umin(x, y); });
         }
         if constexpr (NW > 1) {
             if (sl == 0) *(uint4*)(xbest + (wave * 16 + t) * 4) = make_uint4(best[0], best[1], best[2], best[3]);
@@ -677,7 +696,7 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 cpk |= c << (8 * q);
             }
             if constexpr (!(C4_ABLATE & 8)) {
-                cpk = quarters_reduce(cpk, [](u32 x, u32 y) { return x + y; });
+                cpk = quarters_reduce<NSL>(cpk, [](u32 x, u32 y) { return x + y; });
             }
             if constexpr (NW > 1) {
                 if (sl == 0) xcnt[wave * 16 + t] = cpk;
@@ -687,8 +706,17 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 for (int w2 = 0; w2 < NW; w2++) cpk += xcnt[w2 * 16 + t];
             }
         }
-        // ---- finalise pixel (column 4t+qf) in this lane
+        // ---- finalise the lane's pixel(s) (column 4t + qf)
         if (!ROT || wave == ((y - ya) & (NW - 1))) {
+#pragma unroll
+        for (int jf = 0; jf < NFIN; jf++) {
+        const int qf = qf0 + jf;
+        const int my_col = 4 * t + qf;
+        const int c_out = c0 + my_col;
+        // a column is valid when its whole window lies inside the tile's 64 columns (column granularity, not lane granularity: for a radius that
+        // is not a multiple of 4 the outermost live lanes still produce 4 - R % 4 ... valid columns each)
+        const bool writer = fin && sub_live && (my_col >= R) && (my_col <= 63 - R) && (c_out >= a.cbeg) && (c_out < a.cend);
+        const uint8_t* csrow_r = live_lane ? cs + (size_t)(qf * NLIVE + t - TLO) * CSPB : dump;
         const u32 key = qf == 0 ? best[0] : qf == 1 ? best[1] : qf == 2 ? best[2] : best[3];
         const int tsum = (int)(qf == 0 ? tsum_q[0] : qf == 1 ? tsum_q[1] : qf == 2 ? tsum_q[2] : tsum_q[3]);
         const int ngle = (int)((cpk >> (8 * qf)) & 0xFFu);
@@ -784,12 +812,13 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 else cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
             }
         }
+        }   // the lane's pixels
         }   // finalising wave
         if (!(C4_ABLATE & 1)) sub_regs(RF ? read_slot(1) : read_row(y - R));
     }
 }
 
-template <int NG, int R, int NW, bool RF>
+template <int NG, int R, int NW, bool RF, int NSUB = 1>
 __global__ void __launch_bounds__(64 * NW, C4_MINW) k_bm_c4(BmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -819,16 +848,17 @@ __global__ void __launch_bounds__(64 * NW, C4_MINW) k_bm_c4(BmArgs a)
     // interior tile: no column of the tile is touched by the right-image clamp (rofs + clamp(cc, -rofs, w - ndisp - rofs) + d)
     const bool interior = c0 >= -a.rofs && c0 + 63 <= a.w - a.ndisp - a.rofs;
 #ifdef C4_NO_PF
-    bm_c4_tile<NG, R, NW, false, RF>(a, smem_raw, c0, ya, yb, img);
+    bm_c4_tile<NG, R, NW, false, RF, NSUB>(a, smem_raw, c0, ya, yb, img);
 #else
-    if (interior) bm_c4_tile<NG, R, NW, true, RF>(a, smem_raw, c0, ya, yb, img);
-    else bm_c4_tile<NG, R, NW, false, RF>(a, smem_raw, c0, ya, yb, img);
+    if (interior) bm_c4_tile<NG, R, NW, true, RF, NSUB>(a, smem_raw, c0, ya, yb, img);
+    else bm_c4_tile<NG, R, NW, false, RF, NSUB>(a, smem_raw, c0, ya, yb, img);
 #endif
 }
 
-template <int NG, int R, int NW, bool RF>
-int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
+template <int NG, int R, int NW, bool RF, int NSUB = 1>
+int launch_c4_rf(const BmArgs& a, int batch_images, hipStream_t st, const BmLaunchCtx* ctx)
 {
+    const int batch = (batch_images + NSUB - 1) / NSUB;      // work items along the image axis: images, or pairs of images
     // measurement knobs (tools/chunk_sweep.sh; compiled in only with -DC4_MEASURE_KNOBS, never in the product build -- a stray environment
     // variable must not change occupancy or chunking in production): GIP_C4_LDS_PAD=n allocates n more bytes of LDS per workgroup,
     // GIP_C4_CHUNKS=n forces the chunk count; both read once
@@ -838,7 +868,7 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
 #else
     constexpr int env_pad = 0, env_chunks = 0;
 #endif
-    size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1) + (size_t)(env_pad > 0 ? env_pad : 0);
+    size_t sh = c4_lds_bytes(NG, R, NW, RF ? 2 : 2 * R + 1, NSUB) + (size_t)(env_pad > 0 ? env_pad : 0);
     const int ncols = a.cend - a.cbeg;
     const int ntiles = (ncols + (64 - 2 * R) - 1) / (64 - 2 * R);
     const int nrows = a.row1 - a.row0;
@@ -866,7 +896,7 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
     if (vgpr_alloc == 0) {
         hipFuncAttributes fa;
         vgpr_alloc = 128;
-        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW, RF>) == hipSuccess && fa.numRegs > 0) vgpr_alloc = (fa.numRegs + 7) & ~7;
+        if (hipFuncGetAttributes(&fa, (const void*)k_bm_c4<NG, R, NW, RF, NSUB>) == hipSuccess && fa.numRegs > 0) vgpr_alloc = (fa.numRegs + 7) & ~7;
         vgpr_alloc_c.store(vgpr_alloc, std::memory_order_relaxed);
     }
     const int vgpr_waves = 512 / vgpr_alloc < 1 ? 1 : (512 / vgpr_alloc > 8 ? 8 : 512 / vgpr_alloc);
@@ -908,13 +938,13 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
     BmArgs b = a;
     b.rows_per_chunk = (nrows + nch - 1) / nch;
     nch = (nrows + b.rows_per_chunk - 1) / b.rows_per_chunk;
-    b.ntiles = ntiles; b.nchunks = nch; b.nimg = batch;
+    b.ntiles = ntiles; b.nchunks = nch; b.nimg = batch; b.batch = batch_images;
 #if C4_XCD_MAP
     const dim3 grid((unsigned)(8 * (((size_t)ntiles * nch * batch + 7) / 8)));
 #else
     const dim3 grid(ntiles, nch, batch);
 #endif
-    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW, RF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (sh > 64 * 1024) GIP_HIP_CHECK(hipFuncSetAttribute((const void*)k_bm_c4<NG, R, NW, RF, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     // the matcher may run on a stream of its own (BmLaunchCtx::matcher_stream), fenced by events on both sides
     hipStream_t ks = st;
     const bool forked = ctx && ctx->matcher_stream && ctx->matcher_stream != st;
@@ -929,8 +959,8 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
     hipEvent_t ev_start = ctx ? ctx->ev0 : nullptr;
     hipEvent_t ev_stop = ctx ? ctx->ev1 : nullptr;
     if (forked && !ev_stop) ev_stop = ctx->join;
-    if (ev_start || ev_stop) hipExtLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, ev_start, ev_stop, 0, b);
-    else hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF>), grid, dim3(64 * NW), sh, ks, b);
+    if (ev_start || ev_stop) hipExtLaunchKernelGGL((k_bm_c4<NG, R, NW, RF, NSUB>), grid, dim3(64 * NW), sh, ks, ev_start, ev_stop, 0, b);
+    else hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF, NSUB>), grid, dim3(64 * NW), sh, ks, b);
     GIP_LAUNCH_CHECK();
     if (forked) GIP_HIP_CHECK(hipStreamWaitEvent(st, ev_stop, 0));
     return GIP_OK;
@@ -941,15 +971,20 @@ int launch_c4_rf(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* 
 // those out and the STEP gets 1.5-3 % longer although the matcher gets 2-11 % shorter (same-box A/B, tools/bench_ab.sh).  So: refetch
 // when the matcher is launched on the caller's own stream (single calls, gip_process_pair, one batch in flight), the ring form when the
 // caller hands over a separate matcher stream (BmLaunchCtx::matcher_stream -- the batch pipeline with several batches in flight).
-template <int NG, int R, int NW>
+template <int NG, int R, int NW, int NSUB = 1>
 int launch_c4(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx)
 {
-    if constexpr (c4_refetch(NG, R, NW)) {
+    if constexpr (c4_refetch(NG, R, NW, NSUB)) {
         const bool pipelined = ctx && (ctx->co_scheduled || (ctx->matcher_stream && ctx->matcher_stream != st));
-        if (!pipelined) return launch_c4_rf<NG, R, NW, true>(a, batch, st, ctx);
+        if (!pipelined) return launch_c4_rf<NG, R, NW, true, NSUB>(a, batch, st, ctx);
     }
-    return launch_c4_rf<NG, R, NW, false>(a, batch, st, ctx);
+    return launch_c4_rf<NG, R, NW, false, NSUB>(a, batch, st, ctx);
 }
+
+// C4_PAIR: 1 = disparity counts up to 64 run two images of the batch per wave (NSUB = 2) whenever the batch has at least two
+#ifndef C4_PAIR
+#define C4_PAIR 1
+#endif
 
 // (groups per slice, waves) for a disparity count: ndisp = 16 * NG * NW.  The wave counts are measured choices (tools/bm_ab.py,
 // DESIGN.md 3.1): 2 or 4 waves are 12 % slower at ndisp 128 (any batch size), 2 waves are 38 % faster at ndisp 192 (4 waves: 28 %),
@@ -958,6 +993,19 @@ template <int R>
 int dispatch_ndisp(const BmArgs& a, int batch, hipStream_t st, const BmLaunchCtx* ctx, bool* handled)
 {
     *handled = true;
+#if C4_PAIR
+    // Two images per wave (NSUB = 2) for ndisp <= 48 when the batch is large enough to fill the chip with half as many workgroups
+    // (profiles/r03_pair_kernel.txt: (48, 19) 254.5 M -> 227.5 M wave-instructions, -3 % alone, +2.6 % pairs/s pipelined; ndisp 64 needs NG = 8,
+    // 189 VGPRs = two waves per SIMD, and LOSES 7 %; batches of 3 or 5 images lose 20-40 %: too few workgroups).
+    if (batch >= 8) {
+        switch (a.ndisp) {
+        case 16: return launch_c4<2, R, 1, 2>(a, batch, st, ctx);
+        case 32: return launch_c4<4, R, 1, 2>(a, batch, st, ctx);
+        case 48: return launch_c4<6, R, 1, 2>(a, batch, st, ctx);
+        default: break;
+        }
+    }
+#endif
     switch (a.ndisp) {
     case 16: return launch_c4<1, R, 1>(a, batch, st, ctx);
     case 32: return launch_c4<2, R, 1>(a, batch, st, ctx);

@@ -507,3 +507,22 @@ def test_bm_extreme_uniqueness_and_cost_range(gpu, oracle, uniq, block, cap):
     exp = oracle.stereobm(rl, rr, oracle.bm_params(**kw))
     got = _n(K.stereobm(_t(rl, gpu), _t(rr, gpu), K.bm_params(**kw)))
     assert np.array_equal(got, exp) and (exp != -16).mean() > 0.05
+
+
+@pytest.mark.parametrize("nd,block,batch,mind,d12", [(48, 19, 9, 0, 1), (16, 5, 8, 0, 1), (32, 9, 11, -8, 1), (48, 11, 8, 5, -1), (32, 21, 13, 0, 0), (48, 9, 2, 0, 1)])
+def test_stereobm_two_images_per_wave(gpu, oracle, nd, block, batch, mind, d12):
+    """Disparity counts up to 48 run TWO images of the batch per wavefront once the batch has eight images (NSUB = 2 in
+    k_stereobm_c4_impl.h: one image per 32-lane half, two disparity slices each, a lane finalises two pixels; an odd batch leaves the
+    last pair half empty).  Every image of the batch is different and every one must equal the oracle's cv::StereoBM::compute; the last
+    case (batch 2) stays on the one-image-per-wave kernel."""
+    from ros_gpu_stereo_processor_amd import kernels as K
+    w, h = 331, 57            # odd sizes: border tiles on both sides, ragged last tile
+    pairs = [synth.rectified_pair(w, h, max(16, nd - 8), seed=4000 + 17 * i + nd)[:2] for i in range(batch)]
+    L = np.stack([p[0] for p in pairs])
+    R = np.stack([p[1] for p in pairs])
+    kw = dict(block_size=block, num_disparities=nd, min_disparity=mind, texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=d12)
+    got = _n(K.stereobm(_t(L, gpu), _t(R, gpu), K.bm_params(**kw)))
+    po = oracle.bm_params(**kw)
+    for i in range(batch):
+        assert np.array_equal(got[i], oracle.stereobm(pairs[i][0], pairs[i][1], po)), i
+    assert (got != (mind - 1) * 16).mean() > 0.1
