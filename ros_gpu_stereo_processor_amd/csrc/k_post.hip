@@ -193,6 +193,9 @@ __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, f
 // next to the matcher of another batch against 29 us alone: the matcher keeps every CU's 160 KB full with 20 KB workgroups that are
 // replaced one at a time, so a 57 KB request starves.  At 10 KB it takes 99 us co-scheduled (the ~3x every small kernel stretches by);
 // the global merge of the strip seams (k_spk_cross) grows from 17 to 31 us, throughput is unchanged (profiles/r02_stretch.txt).
+#ifndef SPK_SCAN4_MIN_W
+#define SPK_SCAN4_MIN_W 256     /* rows at least this wide are scanned four pixels per lane (k_spk_scan4), narrower ones two (k_spk_scan2) */
+#endif
 constexpr int SPK_STRIP = SPK_STRIP_N;        // rows per strip
 constexpr int SPK_CAP = SPK_CAP_N;        // runs per strip the LDS level can hold (else the strip is merged globally)
 constexpr int SPK_TPB = 256;
@@ -400,6 +403,94 @@ __global__ void __launch_bounds__(64) k_spk_scan2(const int16_t* __restrict__ di
         n_join += __popcll(jm0) + __popcll(jm1);
         n_run += __popcll(s0) + __popcll(s1);
         carry_start = __shfl(rs1, 63);
+    }
+    if (lane == 0) {
+        S.nrun[blockIdx.z * (size_t)h + y] = n_run;
+        S.njoin[blockIdx.z * (size_t)h + y] = n_join;
+    }
+}
+
+// The same scan with FOUR pixels per lane (256 columns per step, 8-byte loads and stores): the loop is a chain of ballots and prefix
+// counts whose cost per step hardly depends on how many pixels a lane carries, so four pixels per lane halve the steps of a row again
+// (a 4096-column row: 16 steps instead of 32; k_spk_scan2 took 30 us for the 540 rows of a quarter of a 4096x2160 frame, one wave per
+// row).  Same conditions as k_spk_scan2 (even width, 4-byte aligned rows); a lane whose quad straddles the row end carries invalid pixels.
+__global__ void __launch_bounds__(64) k_spk_scan4(const int16_t* __restrict__ disp, size_t dpitch, SpkScratch S, int w, int h, int new_val,
+                                                   int max_diff, size_t dbs)
+{
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const int16_t* d0 = (const int16_t*)((const uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
+    const int16_t* d1 = d0 + dpitch;
+    const bool has_next = y + 1 < h;
+    const size_t base = blockIdx.z * (size_t)w * h + (size_t)y * w;
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= me
+    const unsigned long long lt = le >> 1;                                           // lanes <  me
+    const u32 nvp = (u32)(unsigned short)new_val * 0x10001u;                         // two invalid pixels
+    // four pixels from column x (x even): two dwords, each predicated on its own pair lying inside the row
+    auto load4 = [&](const int16_t* row, int x, bool on) -> uint2 {
+        uint2 v = make_uint2(nvp, nvp);
+        if (on && x + 3 < w) v = *(const uint2*)(row + x);          // (4-byte aligned: rows and x are even counts of int16)
+        else if (on && x + 1 < w) v.x = *(const u32*)(row + x);
+        return v;
+    };
+    int n_run = 0, n_join = 0, carry_start = 0;
+    int pv = new_val, pb = new_val;                 // last pixel of the previous step (rows y and y+1)
+    uint2 nV = load4(d0, 4 * lane, true), nB = load4(d1, 4 * lane, has_next);
+    for (int c0 = 0; c0 < w; c0 += 256) {
+        const int x0 = c0 + 4 * lane;
+        const uint2 V = nV, B = nB;
+        nV = load4(d0, x0 + 256, c0 + 256 < w);
+        nB = load4(d1, x0 + 256, has_next && c0 + 256 < w);
+        int v[4] = {(short)(V.x & 0xFFFFu), (short)(V.x >> 16), (short)(V.y & 0xFFFFu), (short)(V.y >> 16)};
+        int b[4] = {(short)(B.x & 0xFFFFu), (short)(B.x >> 16), (short)(B.y & 0xFFFFu), (short)(B.y >> 16)};
+        int vl = __shfl_up(v[3], 1), bl = __shfl_up(b[3], 1), vr = __shfl_down(v[0], 1);
+        const int nfirst = (short)((u32)__shfl((int)nV.x, 0) & 0xFFFFu);
+        if (lane == 0) { vl = pv; bl = pb; }
+        if (lane == 63) vr = nfirst;
+        pv = __shfl(v[3], 63);
+        pb = __shfl(b[3], 63);
+        bool valid[4], cl[4], st[4], jn[4];
+        unsigned long long sm[4], jm[4];
+        int below = 0, pm = -1;                     // starts in lower lanes; position (in this step) of the latest of them
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int left = i == 0 ? vl : v[i - 1], lbelow = i == 0 ? bl : b[i - 1];
+            valid[i] = v[i] != new_val;
+            cl[i] = spk_conn(left, v[i], new_val, max_diff);
+            st[i] = valid[i] && !cl[i];
+            // vertical join, unless the pair one column to the left already joins the same two runs
+            jn[i] = spk_conn(v[i], b[i], new_val, max_diff) && !(cl[i] && spk_conn(lbelow, b[i], new_val, max_diff) && spk_conn(left, lbelow, new_val, max_diff));
+            sm[i] = __ballot(st[i]);
+            jm[i] = __ballot(jn[i]);
+            const unsigned long long m = sm[i] & lt;
+            below += __popcll(m);
+            const int p = m ? 4 * (63 - __builtin_clzll(m)) + i : -1;
+            pm = p > pm ? p : pm;
+        }
+        int ord[4], rs[4];
+        int acc = n_run + below - 1, cur = pm >= 0 ? c0 + pm : carry_start;
+        int jp = n_join + __popcll(jm[0] & lt) + __popcll(jm[1] & lt) + __popcll(jm[2] & lt) + __popcll(jm[3] & lt);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (st[i]) { acc++; cur = x0 + i; }
+            ord[i] = acc;
+            rs[i] = cur;
+        }
+        if (x0 < w) {
+            const u32 o0 = (valid[0] ? (u32)ord[0] : 0xFFFFu) | ((valid[1] ? (u32)ord[1] : 0xFFFFu) << 16);
+            const u32 o1 = (valid[2] ? (u32)ord[2] : 0xFFFFu) | ((valid[3] ? (u32)ord[3] : 0xFFFFu) << 16);
+            if (x0 + 3 < w) *(uint2*)(S.ord16 + base + x0) = make_uint2(o0, o1);
+            else *(u32*)(S.ord16 + base + x0) = o0;                  // (x0 + 1 < w: the width is even)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int right = i == 3 ? vr : v[i + 1];
+            if (valid[i] && !spk_conn(v[i], right, new_val, max_diff)) S.runlist[base + ord[i]] = (u32)rs[i] | ((u32)(x0 + i - rs[i] + 1) << 16);   // closes its run
+            if (jn[i]) S.joinlist[base + jp] = (u32)ord[i] | ((u32)(x0 + i) << 16);
+            jp += jn[i] ? 1 : 0;
+        }
+        n_join += __popcll(jm[0]) + __popcll(jm[1]) + __popcll(jm[2]) + __popcll(jm[3]);
+        n_run += __popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3]);
+        carry_start = __shfl(rs[3], 63);
     }
     if (lane == 0) {
         S.nrun[blockIdx.z * (size_t)h + y] = n_run;
@@ -962,7 +1053,8 @@ int gipk_speckle_label(const int16_t* disp, size_t disp_pitch, int w, int h, int
     const int nstrips = (h + SPK_STRIP - 1) / SPK_STRIP;
     hipStream_t st = (hipStream_t)stream;
     const bool pairs_ok = (w % 2 == 0) && (disp_pitch % 4 == 0) && ((uintptr_t)disp % 4 == 0) && (disp_bstride % 4 == 0) && ((uintptr_t)S.ord16 % 4 == 0);
-    if (pairs_ok) hipLaunchKernelGGL(k_spk_scan2, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
+    if (pairs_ok && w >= SPK_SCAN4_MIN_W) hipLaunchKernelGGL(k_spk_scan4, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
+    else if (pairs_ok) hipLaunchKernelGGL(k_spk_scan2, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     else hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     hipLaunchKernelGGL(k_spk_strip, dim3(nstrips, 1, batch), dim3(SPK_TPB), (size_t)SPK_CAP * 8, st, S, w, h, nstrips);
     if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(SPK_CROSS_TPB), 0, st, S, w, h, nstrips);
