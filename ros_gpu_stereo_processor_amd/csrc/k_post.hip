@@ -926,7 +926,13 @@ __global__ void k_disp_outputs_sq(const int16_t* __restrict__ disp, size_t dpitc
             store_pc2_record(pc + blockIdx.z * obs + ((size_t)y * w + x) * 32, (float)(qx * e.iw), (float)(qy * e.iw), e.z, c[j]);
             continue;
         }
-        float df = (float)d16[j] * alpha;
+        // No table, or a disparity outside its range (never a matcher output).  The compiler hoists this arithmetic above the branch and runs it
+        // for every pixel NEXT TO the table path (89 instead of 72 wave-instructions per pixel, profiles/r03_pmc_sq_all_kernels.txt) -- and the
+        // pipelined step is 0.8 % FASTER with the table than without, and 1.2 % SLOWER when the hoisting is prevented (60 instructions per pixel;
+        // profiles/r03_outputs_table_ab.txt): the dependent table load then sits alone on the critical path of every wave.  Left as the compiler
+        // schedules it.
+        const int dd = d16[j];
+        float df = (float)dd * alpha;
         df = df + beta;
         if (f32out) ((float*)((uint8_t*)f32out + blockIdx.z * fbs))[(size_t)y * w + x] = df;
         if (!pc) continue;
@@ -934,7 +940,7 @@ __global__ void k_disp_outputs_sq(const int16_t* __restrict__ disp, size_t dpitc
         const double iW = 1. / (q[15] + q[14] * d);
         const double X = qx * iW, Y = qy * iW;
         double Z = q[11] * iW;
-        if (d16[j] == filtered) Z = 10000.;
+        if (dd == filtered) Z = 10000.;
         store_pc2_record(pc + blockIdx.z * obs + ((size_t)y * w + x) * 32, (float)X, (float)Y, (float)Z, c[j]);
     }
 }

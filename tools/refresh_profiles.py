@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Copy the round's rocprofv3 summaries from gpurun_out/prof_r02 (written by tools/prof_round.sh on the GPU box) into profiles/ under the
-names profiles/README.md lists, and derive profiles/traffic.json (HBM bytes per matcher launch) and profiles/r02_stretch.txt from them."""
+"""Copy the round's rocprofv3 summaries from gpurun_out/prof_r03 (written by tools/prof_round.sh on the GPU box) into profiles/ under the
+names profiles/README.md lists, and derive profiles/traffic.json (HBM bytes per matcher launch) and profiles/r03_stretch.txt from them."""
 import csv, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_r02"), os.path.join(ROOT, "profiles")
-TAG = "r02"
+SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_r03"), os.path.join(ROOT, "profiles")
+TAG = "r03"
 
 
 def copy(src, dst):
@@ -21,8 +21,9 @@ for wl in ["", "hd1080_", "uhd4k_", "euroc_", "refdefault_"]:
         copy(f"{TAG}_{wl}{d1}kernel_stats.csv", f"{TAG}_{wl}{d1}kernel_stats.csv")
         copy(f"{TAG}_{wl}{d1}bench.json", f"{TAG}_{wl}{d1}bench_under_rocprof.json")
     copy(f"{TAG}_{wl}pmc_sq1_k_bm_c4.txt", f"{TAG}_{wl}pmc_sq1_k_bm_c4.txt")
-for f in ["pmc_sq2_k_bm_c4", "pmc_sq_all_kernels", "pmc_fetch_size", "pmc_write_size", "pmc_calibration"]:
+for f in ["pmc_sq2_k_bm_c4", "pmc_sq_all_kernels", "pmc_fetch_size", "pmc_write_size", "rowsplit4_kernel_stats", "rowsplit4_serial"]:
     copy(f"{TAG}_{f}.txt", f"{TAG}_{f}.txt")
+copy(f"{TAG}_rowsplit_bench.json", f"{TAG}_rowsplit_bench.json")
 
 
 def counter_of(path, kernel, counter):
@@ -49,7 +50,7 @@ if fetch_kb is not None and write_kb is not None:
                "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
                "note": "rocprofv3 FETCH_SIZE reads exactly half of the streamed bytes on gfx950 at every access width (profiles/r02_pmc_calibration.txt: "
                        "1 GiB copy kernels, 1/2/4/8/16 B per lane), WRITE_SIZE is exact; traffic = 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes "
-                       "(r02_pmc_fetch_size.txt, r02_pmc_write_size.txt)"}
+                       "(r03_pmc_fetch_size.txt, r03_pmc_write_size.txt)"}
     json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
     print("traffic.json: %.1f MB per launch" % (traffic["hbm_bytes_per_launch"] / 1e6))
 
@@ -66,7 +67,7 @@ def stats(path):
 alone, cos = stats(os.path.join(DST, f"{TAG}_depth1_kernel_stats.csv")), stats(os.path.join(DST, f"{TAG}_kernel_stats.csv"))
 with open(os.path.join(DST, f"{TAG}_stretch.txt"), "w") as f:
     f.write("# per-kernel average duration (us), KITTI workload, 64 pairs per launch: alone (bench.py --depth 1) vs co-scheduled (default: 3 batches in flight,\n"
-            "# matchers on one shared stream), from r02_depth1_kernel_stats.csv / r02_kernel_stats.csv; stretch = co-scheduled / alone\n")
+            "# matchers on one shared stream), from r03_depth1_kernel_stats.csv / r03_kernel_stats.csv; stretch = co-scheduled / alone\n")
     f.write("%-52s %10s %12s %8s\n" % ("kernel", "alone_us", "cosched_us", "stretch"))
     for n in sorted(alone, key=lambda k: -alone[k]):
         if n in cos:
