@@ -40,7 +40,7 @@ WORKLOADS = {
     "euroc": dict(W=752, H=480, NDISP=64, BLOCK=15, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<4,7,1>",
                   name="EuRoC-size 752x480 mono8, ndisp=64 block=15, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
     # the reference constructor's matcher shape, createStereoBM(48, 19) (reference src/GPUStereoProcessor.cpp:18-20), at the KITTI size
-    "refdefault": dict(W=1242, H=375, NDISP=48, BLOCK=19, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<3,9,1>",
+    "refdefault": dict(W=1242, H=375, NDISP=48, BLOCK=19, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<6,9,1,*,2> (two images of the batch per wave)",
                        name="1242x375 mono8, ndisp=48 block=19 (the reference's createStereoBM(48, 19)), full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
                             "->speckle(800,5)->f32 disparity+PointCloud2"),
 }
