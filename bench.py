@@ -542,7 +542,8 @@ def main():
             out["secondary"] = sec
             out["verified"] = bool(out.get("verified")) and all(r.get("verified") is not False for r in sec)
         # ... and BASELINE configs[4] (row-tile split of one 4096x2160 frame) when there are devices to split over
-        if world >= 4 and not rehearse and not args.no_secondary and os.environ.get("GIP_BENCH_NO_ROWSPLIT") != "1":
+        # (GIP_BENCH_FORCE_ROWSPLIT=1: rehearsal of this branch on a box with fewer devices -- the tiles then share devices)
+        if ((world >= 4 and not rehearse) or os.environ.get("GIP_BENCH_FORCE_ROWSPLIT") == "1") and not args.no_secondary and os.environ.get("GIP_BENCH_NO_ROWSPLIT") != "1":
             out["rowsplit"] = None       # filled in below, once the other ranks have left their devices
     # the frame-sharded job ends here for everybody; the other ranks release their GPUs before rank 0 starts the row-split child
     if world > 1:
