@@ -517,6 +517,9 @@ typedef struct gip_rowsplit_timing {
     float front_ms, halo_ms, match_ms, gather_ms, post_ms, total_ms;
 } gip_rowsplit_timing;
 
+/* the plan alone (host only, no device needed): own rows [y0, y1), extended rows [e0, e1) of tile `tile` and the halo row count for a
+ * frame of `height` rows cut into n_tiles tiles with these matcher parameters; INVALID_ARG when the tiles would be thinner than halo + 2 */
+int gip_rowsplit_plan_rows(int height, int n_tiles, const gip_bm_params *params, int tile, int *y0, int *y1, int *e0, int *e1, int *halo);
 int gip_rowsplit_open(const gip_camera_info *left, const gip_camera_info *right, const gip_bm_params *params, int max_speckle_size,
                       double max_speckle_diff, const gip_rowsplit_config *cfg, gip_rowsplit *out);
 int gip_rowsplit_close(gip_rowsplit rs);

@@ -213,6 +213,7 @@ PROTOTYPES = {
     "gipk_speckle_border_record": (_i, [_vp, _sz, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "gipk_speckle_border_gather": (_i, [_vp, _i, _i, _vp, _vp]),
     "gipk_speckle_border_merge": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "gip_rowsplit_plan_rows": (_i, [_i, _i, C.POINTER(BMParams), _i] + [C.POINTER(_i)] * 5),
     "gip_rowsplit_open": (_i, [C.POINTER(CameraInfo), C.POINTER(CameraInfo), C.POINTER(BMParams), _i, _d, C.POINTER(RowSplitConfig), C.POINTER(_vp)]),
     "gip_rowsplit_close": (_i, [_vp]),
     "gip_rowsplit_last_error": (C.c_char_p, [_vp]),

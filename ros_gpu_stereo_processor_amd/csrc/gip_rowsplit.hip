@@ -406,6 +406,23 @@ int timing_of(gip_rowsplit_s* rs, Tile& T, gip_rowsplit_timing* out)
 
 extern "C" {
 
+// the plan alone (host only, no device): rows of tile `tile` of an n_tiles split of a frame `height` rows tall for these matcher parameters
+int gip_rowsplit_plan_rows(int height, int n_tiles, const gip_bm_params* params, int tile, int* y0, int* y1, int* e0, int* e1, int* halo)
+{
+    if (!params || height <= 0 || n_tiles < 1 || n_tiles > 16 || tile < 0 || tile >= n_tiles) return GIP_ERR_INVALID_ARG;
+    const int hl = halo_rows(*params), base = height / n_tiles, rem = height % n_tiles;
+    if (n_tiles > 1 && base < hl + 2) return GIP_ERR_INVALID_ARG;        // a tile must be taller than the rows it lends to its neighbours
+    const int a = tile * base + (tile < rem ? tile : rem), b = a + base + (tile < rem ? 1 : 0);
+    int x0, x1;
+    extended_range(height, a, b, hl, &x0, &x1);
+    if (y0) *y0 = a;
+    if (y1) *y1 = b;
+    if (e0) *e0 = x0;
+    if (e1) *e1 = x1;
+    if (halo) *halo = hl;
+    return GIP_OK;
+}
+
 int gip_rowsplit_open(const gip_camera_info* left, const gip_camera_info* right, const gip_bm_params* params, int max_speckle_size, double max_speckle_diff,
                       const gip_rowsplit_config* cfg, gip_rowsplit* out)
 {
@@ -431,19 +448,13 @@ int gip_rowsplit_open(const gip_camera_info* left, const gip_camera_info* right,
     if (gip_validate_bm_params(&rs->bp, w, hh) != GIP_OK) return fail(GIP_ERR_INVALID_ARG);
     // the plan: contiguous, near-equal row ranges; a tile must be at least as tall as the halo it lends to its neighbours
     rs->tiles.resize(N);
-    const int base = hh / N, rem = hh % N;
-    int y = 0;
     for (int t = 0; t < N; t++) {
         Tile& T = rs->tiles[t];
         T.t = t;
-        T.y0 = y;
-        y += base + (t < rem ? 1 : 0);
-        T.y1 = y;
-        extended_range(hh, T.y0, T.y1, rs->halo, &T.e0, &T.e1);
+        if (gip_rowsplit_plan_rows(hh, N, &rs->bp, t, &T.y0, &T.y1, &T.e0, &T.e1, nullptr) != GIP_OK) return fail(GIP_ERR_INVALID_ARG);
         T.device = cfg->devices[t] >= 0 ? cfg->devices[t] : t % ndev;
         if (T.device >= ndev) return fail(GIP_ERR_INVALID_ARG);
     }
-    if (N > 1 && base < rs->halo + 2) return fail(GIP_ERR_INVALID_ARG);
     const bool want_f32 = (cfg->outputs & GIP_TOPIC_DISPARITY) != 0, want_pc = (cfg->outputs & GIP_TOPIC_POINTCLOUD) != 0;
     const int cn = raw_channels(cfg->encoding);
     for (Tile& T : rs->tiles) {

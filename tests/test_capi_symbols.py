@@ -139,3 +139,38 @@ def test_uniqueness_threshold_multiply_shift_identity():
         K = (u * (1 << 23) + 99) // 100
         assert K < (1 << 24)
         assert np.array_equal((ms * u) // 100, (ms * K) >> 23), u
+
+
+def test_rowsplit_plan_is_host_logic_and_matches_the_distributed_form(built_lib):
+    """gip_rowsplit_plan_rows needs no device: the native row split (gip_rowsplit_*) and the torch.distributed form (rowsplit.py) must cut
+    a frame into the same tiles with the same halos -- contiguous cover, even first extended row, XSOBEL / NORMALIZED_RESPONSE halo,
+    rejection of tiles thinner than the rows they lend; and without a device the split itself cannot be opened (no CPU fallback)."""
+    import ctypes as C
+    from ros_gpu_stereo_processor_amd import capi, rowsplit as RS
+    L = capi.lib()
+    for height, n, block, ptype, psize in [(2160, 4, 15, 1, 9), (375, 3, 9, 1, 9), (301, 5, 11, 1, 9), (1080, 8, 21, 0, 9), (480, 2, 31, 0, 21), (97, 1, 5, 1, 5)]:
+        p = capi.BMParams(prefilter_type=ptype, prefilter_size=psize, prefilter_cap=31, block_size=block, min_disparity=0, num_disparities=64, texture_threshold=10,
+                          uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+        halo = RS.halo_rows(block, ptype, psize)
+        ranges = RS.plan(height, n)
+        prev_end = 0
+        for t in range(n):
+            v = [C.c_int() for _ in range(5)]
+            assert L.gip_rowsplit_plan_rows(height, n, C.byref(p), t, *[C.byref(x) for x in v]) == capi.OK
+            y0, y1, e0, e1, hl = [x.value for x in v]
+            assert (y0, y1) == ranges[t] and y0 == prev_end and hl == halo
+            assert (e0, e1) == RS.extended_range(height, y0, y1, halo) and e0 % 2 == 0 and e0 <= y0 and e1 >= y1
+            prev_end = y1
+        assert prev_end == height
+    p = capi.BMParams(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=21, min_disparity=0, num_disparities=64, texture_threshold=10,
+                      uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    v = [C.c_int() for _ in range(5)]
+    assert L.gip_rowsplit_plan_rows(100, 8, C.byref(p), 0, *[C.byref(x) for x in v]) == capi.ERR_INVALID_ARG      # 12-row tiles, 11 + 2 needed
+    assert L.gip_rowsplit_plan_rows(100, 17, C.byref(p), 0, *[C.byref(x) for x in v]) == capi.ERR_INVALID_ARG
+    import torch
+    if not torch.cuda.is_available():
+        cfg = capi.RowSplitConfig()
+        cfg.width, cfg.height, cfg.n_tiles = 640, 480, 2
+        ci = capi.CameraInfo()
+        h = C.c_void_p()
+        assert L.gip_rowsplit_open(C.byref(ci), C.byref(ci), C.byref(p), 0, 0.0, C.byref(cfg), C.byref(h)) == capi.ERR_NO_DEVICE
