@@ -299,9 +299,11 @@ def rowsplit_native(args, wl):
             dev_frames[d] = ([torch.from_numpy(x).to("cuda:%d" % d) for x in lraw], [torch.from_numpy(x).to("cuda:%d" % d) for x in rraw])
         return dev_frames[d]
 
-    def measure(nt, depth=2):
+    def measure(nt, depth=2, halo_mode=None, gather_mode=0):
+        halo_mode = args.halo_mode if halo_mode is None else halo_mode
         devices = [t % ndev for t in range(nt)]
-        groups = [RS.RowSplit(W, H, calib, params, nt, ENCODING, outputs, SPECKLE_SIZE, SPECKLE_DIFF, devices=devices, halo_mode=args.halo_mode, host_threads=args.host_threads)
+        groups = [RS.RowSplit(W, H, calib, params, nt, ENCODING, outputs, SPECKLE_SIZE, SPECKLE_DIFF, devices=devices, halo_mode=halo_mode, host_threads=args.host_threads,
+                              gather_mode=gather_mode)
                   for _ in range(depth)]
         for k, g in enumerate(groups):          # group k always works on frame k mod 2: inputs resident in HBM before the timed region
             for t, d in enumerate(devices):
@@ -333,7 +335,9 @@ def rowsplit_native(args, wl):
         d16 = groups[0].download(want_f32=False, want_cloud=False)[0]
         for g in groups:
             g.close()
-        rec = {"tiles": nt, "devices": devices, "frames_in_flight": depth, "frames_per_s": round(args.steps / dt, 2), "ms_per_frame": round(1e3 * dt / args.steps, 4),
+        rec = {"tiles": nt, "devices": devices, "halo": "every tile rectifies its own halo rows" if halo_mode else "hipMemcpyPeerAsync from the neighbours",
+               "border_records": {0: "auto (gather kernel when the tiles share a device, else peer copies)", 1: "peer copies", 2: "gather kernel reading peer memory in place"}[gather_mode],
+               "frames_in_flight": depth, "frames_per_s": round(args.steps / dt, 2), "ms_per_frame": round(1e3 * dt / args.steps, 4),
                "latency_ms_p50": round(lat[len(lat) // 2], 4), "per_tile_noncomm_ms": noncomm, "per_tile_noncomm_ms_max": max(noncomm),
                "per_tile_comm_ms_alone": [round(x["halo_ms"] + x["gather_ms"], 4) for x in serial],
                "per_tile_gpu_ms_concurrent": [round(x["total_ms"], 4) for x in conc],
@@ -341,8 +345,20 @@ def rowsplit_native(args, wl):
         return rec, d16
 
     records, verified, exp = [], None, None
-    for nt in counts + ([extra_one_device] if extra_one_device else []):
-        rec, d16 = measure(nt)
+    todo = [(nt, None, 0) for nt in counts + ([extra_one_device] if extra_one_device else [])]
+    if args.variants and tiles > 1:
+        # the other ways to move the halo rows and the border records, at the full tile count: which is faster is a property of the node's links
+        todo += [(tiles, 1, 0), (tiles, 0, 2), (tiles, 1, 2)]
+    for nt, hm, gm in todo:
+        try:
+            rec, d16 = measure(nt, halo_mode=hm, gather_mode=gm)
+        except Exception as e:       # noqa: BLE001 -- a variant that does not run on this node must not take the other records down
+            if hm is None and gm == 0:
+                raise
+            records.append({"tiles": nt, "halo_mode": hm, "gather_mode": gm, "error": repr(e)})
+            continue
+        if hm is not None or gm:
+            rec["variant"] = True
         if nt == extra_one_device and nt not in counts:
             rec["note"] = "%d handles sharing %d device(s): concurrency without more hardware; the per-tile times alone are what a rank on its own GPU would see" % (nt, ndev)
         if not args.no_verify:
@@ -354,7 +370,7 @@ def rowsplit_native(args, wl):
             rec["verified"] = ok
             verified = ok if verified is None else (verified and ok)
         records.append(rec)
-    main_rec = [r for r in records if r["tiles"] == tiles][0]
+    main_rec = [r for r in records if r["tiles"] == tiles and not r.get("variant") and "error" not in r][0]
     out = {"metric": metric_name(wl), "value": main_rec["frames_per_s"], "unit": "stereo pairs/s", "n_gpus": min(tiles, ndev), "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": main_rec["ms_per_frame"], "ms_per_frame": main_rec["ms_per_frame"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
            "data": "synthetic",
@@ -441,7 +457,7 @@ def rowsplit_secondary(world, timeout_s=150):
     (the other ranks' devices are idle by then) and embeds its record.  A child with a time limit: whatever goes wrong there costs the
     secondary record only, never the main line."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "uhd4k", "--rowsplit", "--tiles", "4", "--steps", "60", "--warmup", "6", "--no-extra"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "uhd4k", "--rowsplit", "--tiles", "4", "--steps", "60", "--warmup", "6", "--no-extra", "--variants"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
                                                             "TORCHELASTIC_RUN_ID", "MASTER_PORT")}
     try:
@@ -484,6 +500,7 @@ def main():
                     "the visible devices")
     ap.add_argument("--halo-mode", type=int, default=0, choices=[0, 1], help="--rowsplit: 0 = neighbours exchange rectified halo rows (hipMemcpyPeerAsync), 1 = every tile rectifies its own halo rows")
     ap.add_argument("--host-threads", type=int, default=0, choices=[0, 1], help="--rowsplit: 0 = one enqueueing host thread per tile, 1 = the calling thread enqueues everything")
+    ap.add_argument("--variants", action="store_true", help="--rowsplit: also measure the other halo / border-record transports at the full tile count")
     ap.add_argument("--no-extra", action="store_true", help="--rowsplit: skip the additional 4-handle record on fewer than 4 devices")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of one frame of the timed configuration with the oracle chain")
     ap.add_argument("--no-secondary", action="store_true", help="only the metric's own workload: no hd1080 / refdefault / utest_timing records, no row-split child at N >= 4")

@@ -172,3 +172,30 @@ def test_config5_4k_rowsplit_four_handles_matches_oracle(gpu, oracle):
     exp = _oracle_chain(oracle, lraw, rraw, calib, w, h, kw, "mono8", 800, 80)
     _check(got, exp)
     assert (exp[0] != -16).mean() > 0.2
+
+
+@pytest.mark.parametrize("nd,block,mind,uniq,d12,tex,spk,outputs_pc", [(32, 9, -8, 0, -1, 0, 0, True), (48, 19, 4, 15, 0, 3, 40, True), (64, 5, 0, 25, 2, 10, 3000, False),
+                                                                       (16, 31, 0, 15, 1, 10, 100, True)])
+def test_rowsplit_native_parameter_corners(gpu, oracle, nd, block, mind, uniq, d12, tex, spk, outputs_pc):
+    """Negative / positive minDisparity (the clamped border columns feed the L/R check), uniqueness and L/R check off, speckle filter off or
+    with a threshold above most components (every tile then has border components that must be kept), the largest block, float disparity
+    only: 3 tiles, the stitched frame against the oracle chain."""
+    from ros_gpu_stereo_processor_amd import capi, rowsplit as RS
+    w, h = 520, 231
+    calib = synth.scaled_calibration(w, h)
+    kw = _kw(nd, block)
+    kw.update(min_disparity=mind, uniqueness_ratio=uniq, disp12_max_diff=d12, texture_threshold=tex)
+    lraw, rraw = _frames(w, h, max(16, nd - 8), 61, "mono8", calib)
+    outputs = capi.TOPIC_DISPARITY | (capi.TOPIC_POINTCLOUD if outputs_pc else 0)
+    rs = RS.RowSplit(w, h, calib, capi.BMParams(**kw), 3, "mono8", outputs, spk, 1.5)
+    rs.upload(lraw, rraw)
+    rs.run()
+    d16, f32, pc = rs.download()
+    rs.close()
+    e16, e32, epc = _oracle_chain(oracle, lraw, rraw, calib, w, h, kw, "mono8", spk, 24)
+    assert np.array_equal(d16, e16) and np.array_equal(f32, e32)
+    if outputs_pc:
+        _check((d16, f32, pc), (e16, e32, epc))
+    else:
+        assert pc is None
+    assert (e16 != (mind - 1) * 16).mean() > 0.05
