@@ -507,6 +507,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-priority", type=int, default=0, help="HIP stream priority of the per-batch streams that carry everything but the matcher (-1 = high)")
     ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
+    ap.add_argument("--no-cloud", action="store_true", help="experiment (NOT the metric's configuration): float disparity only, no PointCloud2 records")
+    ap.add_argument("--chain-cu-mask", default="", help="experiment: PATTERN/PERIOD, e.g. 0x1/4 = the per-batch (non-matcher) streams may use every fourth CU only")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end streaming measurement (host memory in, host memory out)")
     ap.add_argument("--ndisp", type=int, default=0, help="experiment: override the workload's numDisparities (the metric's configuration is the default)")
@@ -602,10 +604,27 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
     # independent units (frame i -> rank i mod N, dist.frame_shard), so no collective follows on the data path.
     calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
     params = capi.BMParams(**bm_kwargs())
-    outputs = capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD
+    outputs = capi.TOPIC_DISPARITY | (0 if args.no_cloud else capi.TOPIC_POINTCLOUD)
     pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True, fused_front_end=args.fused_front_end, batches_in_flight=max(1, depth))
              for _ in range(max(1, depth))]
-    streams = [torch.cuda.Stream(device=dev, priority=args.chain_priority) for _ in pipes]
+    if args.chain_cu_mask:
+        # experiment: the per-batch streams (everything but the matcher) restricted to a subset of the CUs (hipExtStreamCreateWithCUMask), so that the
+        # matcher keeps the other CUs to itself.  The mask is a bit string repeated over the 256 CUs, e.g. 0x1 period 4 = every fourth CU.
+        hip = C.CDLL("libamdhip64.so")
+        pattern, period = [int(x, 0) for x in args.chain_cu_mask.split("/")]
+        bits = 0
+        for i in range(256):
+            if (pattern >> (i % period)) & 1:
+                bits |= 1 << i
+        words = (C.c_uint32 * 8)(*[(bits >> (32 * k)) & 0xFFFFFFFF for k in range(8)])
+        streams = []
+        for _ in pipes:
+            hs = C.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(hs), 8, words)
+            assert rc == 0, "hipExtStreamCreateWithCUMask failed: %d" % rc
+            streams.append(torch.cuda.ExternalStream(hs.value, device=dev))
+    else:
+        streams = [torch.cuda.Stream(device=dev, priority=args.chain_priority) for _ in pipes]
     matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if (len(pipes) > 1 and shared_matcher) else None
     # "two": two matcher streams taken in turn, so that the ragged end of one matcher launch overlaps the start of the next
     matcher_streams = [matcher_stream]
@@ -709,6 +728,9 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
                     cache[sc] = cpu_chain(O, lraw[sc], rraw[sc], calib, omaps, po)
                 e16, epc = cache[sc]
                 g16 = pipes[k].disparity[0].cpu().numpy()
+                if pipes[k].pointcloud is None:
+                    verified = verified and bool(np.array_equal(g16, e16))
+                    continue
                 gpc = pipes[k].pointcloud[0].cpu().numpy()
                 gx, ex = gpc[..., :12].copy().view(np.float32), epc[..., :12].copy().view(np.float32)
                 ok = np.array_equal(g16, e16) and np.array_equal(np.isnan(gx), np.isnan(ex)) and np.array_equal(gpc[..., 12:], epc[..., 12:])
@@ -721,7 +743,7 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt_max / steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"], "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
+            "config": {"workload": wl["name"] + (" [EXPERIMENT: no PointCloud2 output]" if args.no_cloud else ""), "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
                        "parallelism": "frame-sharded x%d: frame g of a %d-frame bag -> rank g mod %d" % (world, BAG_FRAMES, world)},
             "verified": verified,
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
