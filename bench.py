@@ -505,6 +505,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of one frame of the timed configuration with the oracle chain")
     ap.add_argument("--no-secondary", action="store_true", help="only the metric's own workload: no hd1080 / refdefault / utest_timing records, no row-split child at N >= 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plain-streams", action="store_true", help="EXPERIMENT: create the pipeline's streams with torch.cuda.Stream in program order instead of gip_concurrent_streams_create")
     ap.add_argument("--chain-priority", type=int, default=0, help="HIP stream priority of the per-batch streams that carry everything but the matcher (-1 = high)")
     ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
     ap.add_argument("--no-cloud", action="store_true", help="experiment (NOT the metric's configuration): float disparity only, no PointCloud2 records")
@@ -623,9 +624,21 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
             rc = hip.hipExtStreamCreateWithCUMask(C.byref(hs), 8, words)
             assert rc == 0, "hipExtStreamCreateWithCUMask failed: %d" % rc
             streams.append(torch.cuda.ExternalStream(hs.value, device=dev))
-    else:
+    elif args.plain_streams or args.chain_priority or args.matcher_priority:
         streams = [torch.cuda.Stream(device=dev, priority=args.chain_priority) for _ in pipes]
-    matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if (len(pipes) > 1 and shared_matcher) else None
+    else:
+        streams = None
+    want_matcher = len(pipes) > 1 and shared_matcher
+    independent_streams = None
+    if streams is None:
+        # the batch streams and the matcher stream as ONE set of streams that were measured to dispatch side by side (gip_concurrent_streams_create):
+        # which hardware queue a HIP stream lands on depends on every stream the process created before, and a matcher stream that shares a
+        # queue with a batch stream costs 12-25 %
+        handles, independent_streams = capi.concurrent_streams(len(pipes) + (1 if want_matcher else 0), local_rank)
+        ext = [torch.cuda.ExternalStream(hd, device=dev) for hd in handles]
+        streams, matcher_stream = ext[:len(pipes)], (ext[len(pipes)] if want_matcher else None)
+    else:
+        matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if want_matcher else None
     # "two": two matcher streams taken in turn, so that the ragged end of one matcher launch overlaps the start of the next
     matcher_streams = [matcher_stream]
     if args.matcher_stream == "two" and len(pipes) > 1:
@@ -743,7 +756,7 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt_max / steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"] + (" [EXPERIMENT: no PointCloud2 output]" if args.no_cloud else ""), "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
+            "config": {"workload": wl["name"] + (" [EXPERIMENT: no PointCloud2 output]" if args.no_cloud else ""), "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "independent_streams": independent_streams, "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
                        "parallelism": "frame-sharded x%d: frame g of a %d-frame bag -> rank g mod %d" % (world, BAG_FRAMES, world)},
             "verified": verified,
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -178,6 +178,16 @@ const char *gip_last_error(gip_handle h);
 int gip_device(gip_handle h);
 const char *gip_status_string(int status);
 int gip_device_count(void);
+/* n (1..16) new non-blocking streams of `device` that make progress SIDE BY SIDE.  The reference creates its two side streams and lets the
+ * driver overlap them (GPUStereoProcessor.cpp:190-200); on MI355X the runtime maps the streams of a process onto four hardware queues by a
+ * policy of its own, and two streams that land on one queue run strictly one after the other -- the throughput pipeline (three batch
+ * streams + the shared matcher stream, gip_batch_desc::matcher_stream) loses 12-25 % when that happens.  This call measures instead of
+ * guessing: it keeps a candidate stream only if a one-workgroup kernel on it completes while a chip-filling kernel runs on each stream kept
+ * so far (a few milliseconds per candidate, at set-up time; the device should be otherwise idle).  *n_independent (may be NULL) = how many of
+ * the returned streams are mutually concurrent; it is < n only when n exceeds the hardware queues the runtime uses (GPU_MAX_HW_QUEUES) --
+ * the rest of the array is then filled with ordinary streams.  Destroy with gip_concurrent_streams_destroy (or hipStreamDestroy). */
+int gip_concurrent_streams_create(int device, int n, gip_stream *streams, int *n_independent);
+int gip_concurrent_streams_destroy(int device, int n, gip_stream *streams);
 
 /* initStereoModel(CameraInfo, CameraInfo) / (left_cal_file, right_cal_file)  (GPUStereoProcessor.cpp:41-61) */
 int gip_init_stereo_model(gip_handle h, const gip_camera_info *left, const gip_camera_info *right);
@@ -464,7 +474,14 @@ typedef struct gip_batch_desc {
                                 * its own (throughput pipelines): the matcher then leaves a quarter of every SIMD's registers to the small
                                 * kernels of the other batches instead of taking every workgroup slot it can get -- faster alone, slower as
                                 * a pipeline otherwise.  Setting matcher_stream implies > 1 */
+    int32_t phase;             /* GIP_BATCH_WHOLE (0, default): the whole chain.  GIP_BATCH_FRONT: colour, rectify, prefilter and the matcher
+                                * only -- with a matcher_stream the matcher is launched there and `stream` does NOT wait for it.
+                                * GIP_BATCH_BACK (same handle, same descriptor, after its FRONT): wait for that matcher, then L/R check,
+                                * speckle filter and the outputs.  A host that enqueues FRONT(k+1) before BACK(k) software-pipelines the
+                                * batches on TWO streams in all: the matchers back to back on matcher_stream, everything else in order on
+                                * `stream` next to them (handles and buffers: three sets in rotation).  See DESIGN.md section 4 */
 } gip_batch_desc;
+enum { GIP_BATCH_WHOLE = 0, GIP_BATCH_FRONT = 1, GIP_BATCH_BACK = 2 };
 int gip_batch_set_maps_device(gip_handle h, int width, int height, const int16_t *map1_l, const uint16_t *map2_l,
                               const int16_t *map1_r, const uint16_t *map2_r);
 int gip_batch_run(gip_handle h, const gip_batch_desc *desc, gip_stream stream);

@@ -13,6 +13,11 @@
 // ~streaming:=true replaces the reference's one-frame-in-flight cycle (upload, enqueue, waitForAllStreams: src/StereoProcessor.cpp:179-180,
 // :284) for the disparity and pointcloud topics by the pipelined host link (gip_streamer_*): imageCb returns as soon as the pair is in the
 // pinned ring and the messages are published from the streamer's callback, in order.
+#include <algorithm>
+#include <cstdio>
+#include <memory>
+#include <string>
+
 #include <boost/bind.hpp>
 #include <boost/make_shared.hpp>
 #include <boost/thread/recursive_mutex.hpp>

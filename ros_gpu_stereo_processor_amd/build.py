@@ -19,7 +19,7 @@ OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libgpuimageproc_hip.so")
 SOURCES = ["k_stereobm_c4_ra.hip", "k_stereobm_c4_rb.hip", "k_stereobm_c4_rc.hip", "k_stereobm_c4_rd.hip", "k_stereobm_c4_re.hip", "k_stereobm_c4_rf.hip",
            "k_stereobm_c4_rg.hip", "k_image.hip", "k_stereobm.hip", "k_stereobm_c4.hip",
-           "k_stereobm_wide.hip", "k_post.hip", "gip_capi.hip", "gip_rowsplit.hip", "gip_model.cpp", "gip_streamer.cpp", "gip_rosmsg.cpp"]
+           "k_stereobm_wide.hip", "k_post.hip", "gip_capi.hip", "gip_rowsplit.hip", "gip_streams.hip", "gip_model.cpp", "gip_streamer.cpp", "gip_rosmsg.cpp"]
 HEADERS = [os.path.join(CSRC, "gip_internal.h"), os.path.join(CSRC, "gip_model.h"), os.path.join(CSRC, "bm_common.h"), os.path.join(CSRC, "gip_handle_view.h"), os.path.join(CSRC, "k_stereobm_c4_impl.h"),
            os.path.join(ROOT, "include", "gpuimageproc_hip.h")]
 ARCH = os.environ.get("GIP_OFFLOAD_ARCH", "gfx950")

@@ -40,6 +40,7 @@ TOPIC_DEBAYER_COLOR_LEFT, TOPIC_DEBAYER_COLOR_RIGHT = 1 << 2, 1 << 3
 TOPIC_RECTIFY_MONO_LEFT, TOPIC_RECTIFY_MONO_RIGHT = 1 << 4, 1 << 5
 TOPIC_RECTIFY_COLOR_LEFT, TOPIC_RECTIFY_COLOR_RIGHT = 1 << 6, 1 << 7
 TOPIC_DISPARITY, TOPIC_DISPARITY_VIS, TOPIC_POINTCLOUD = 1 << 8, 1 << 9, 1 << 10
+BATCH_WHOLE, BATCH_FRONT, BATCH_BACK = 0, 1, 2    # gip_batch_desc::phase
 
 
 class BMParams(C.Structure):
@@ -82,7 +83,7 @@ class PointCloud2Msg(C.Structure):
 class BatchDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch", C.c_int32), ("encoding", C.c_int32), ("outputs", C.c_uint32),
                 ("left_raw", C.c_void_p), ("right_raw", C.c_void_p), ("disparity", C.c_void_p), ("disparity_f32", C.c_void_p),
-                ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p), ("fused_front_end", C.c_int32), ("batches_in_flight", C.c_int32)]
+                ("pointcloud", C.c_void_p), ("matcher_stream", C.c_void_p), ("fused_front_end", C.c_int32), ("batches_in_flight", C.c_int32), ("phase", C.c_int32)]
 
 
 class StreamerConfig(C.Structure):
@@ -119,6 +120,8 @@ PROTOTYPES = {
     "gip_device": (_i, [_vp]),
     "gip_status_string": (C.c_char_p, [_i]),
     "gip_device_count": (_i, []),
+    "gip_concurrent_streams_create": (_i, [_i, _i, C.POINTER(_vp), C.POINTER(_i)]),
+    "gip_concurrent_streams_destroy": (_i, [_i, _i, C.POINTER(_vp)]),
     "gip_init_stereo_model": (_i, [_vp, C.POINTER(CameraInfo), C.POINTER(CameraInfo)]),
     "gip_init_stereo_model_files": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "gip_is_stereo_model_initialised": (_i, [_vp]),
@@ -263,3 +266,19 @@ def check(status, handle=None):
     if status != OK:
         msg = lib().gip_last_error(handle).decode() if handle else ""
         raise GipError(status, msg)
+
+
+def concurrent_streams(n, device=0):
+    """n HIP stream handles (ints) of `device` that dispatch side by side (gip_concurrent_streams_create), and how many of them are
+    mutually independent.  Wrap them with torch.cuda.ExternalStream to use them from torch; release with release_streams()."""
+    arr = (C.c_void_p * n)()
+    k = C.c_int(0)
+    rc = lib().gip_concurrent_streams_create(device, n, arr, C.byref(k))
+    if rc != 0:
+        raise GipError(rc, "gip_concurrent_streams_create")
+    return [int(arr[i]) for i in range(n)], k.value
+
+
+def release_streams(handles, device=0):
+    arr = (C.c_void_p * len(handles))(*handles)
+    lib().gip_concurrent_streams_destroy(device, len(handles), arr)

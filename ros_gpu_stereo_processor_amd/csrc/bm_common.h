@@ -32,6 +32,8 @@ struct BmLaunchCtx {
     hipStream_t matcher_stream = nullptr;        // launch the matcher here instead of the caller's stream ...
     hipEvent_t fork = nullptr, join = nullptr;   // ... fenced by these two events (required when matcher_stream is set)
     bool co_scheduled = false;                   // kernels of other batches run next to this launch (gip_batch_desc::batches_in_flight > 1)
+    bool defer_join = false;                     // forked launch: do NOT make the caller's stream wait for the matcher; the event to wait for is
+    mutable hipEvent_t pending_join = nullptr;   // left here instead (gip_batch_run's FRONT / BACK phases)
 };
 
 // k_stereobm_c4.hip: column-sum matcher, every output column.  Returns GIP_OK and sets *handled when a kernel

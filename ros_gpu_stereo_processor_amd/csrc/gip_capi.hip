@@ -88,6 +88,9 @@ struct gip_processor {
     int device = 0;
     hipStream_t l_strm = nullptr, r_strm = nullptr;
     hipEvent_t match_fork = nullptr, match_join = nullptr;   // gip_batch_desc::matcher_stream fences
+    bool front_pending = false;                              // gip_batch_run: a FRONT phase waits for its BACK phase
+    hipEvent_t front_join = nullptr;                         //   ... the matcher's completion event of that FRONT phase (one of the events above / tev)
+    int front_cost_u16 = 1;                                  //   ... and the type of its min-SAD plane
     std::unordered_map<int, Slot> slots;
     GipStereoModel model;
     gip_bm_params params{};
@@ -146,7 +149,23 @@ int propagate(gip_handle h, int rc, const char* what)
     return rc;
 }
 
-hipStream_t stream_of(gip_handle h, int slot_or_side) { return (slot_or_side & GIP_SIDE_L) ? h->l_strm : h->r_strm; }
+// The two side streams (GpuStereoProcessor::getStream, GPUStereoProcessor.cpp:190-200) are created on FIRST USE: the runtime multiplexes all
+// streams of a process onto a handful of hardware queues, and streams that share a queue serialise -- a handle that only ever runs
+// gip_batch_run on the caller's streams (throughput pipelines, the streamer's lanes, row-split tiles) must not park two idle streams on
+// them (measured with tools/gip_bench.cpp: three pipelines + a matcher stream next to six idle side streams 49.8 k pairs/s, without them
+// the same as bench.py).  If a stream cannot be created the null stream serves (correct, just not concurrent).
+hipStream_t stream_of(gip_handle h, int slot_or_side)
+{
+    hipStream_t& s = (slot_or_side & GIP_SIDE_L) ? h->l_strm : h->r_strm;
+    if (!s) {
+        (void)hipSetDevice(h->device);
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            s = nullptr;
+        }
+    }
+    return s;
+}
 
 int ensure_dev(gip_handle h, DevBuf& b, size_t bytes)
 {
@@ -181,8 +200,8 @@ int slot_create(gip_handle h, int id, int rows, int cols, int type, Slot** out)
     }
     if (s.cap < need) {
         if (s.d) {
-            H_HIP(h, hipStreamSynchronize(h->l_strm));
-            H_HIP(h, hipStreamSynchronize(h->r_strm));
+            if (h->l_strm) H_HIP(h, hipStreamSynchronize(h->l_strm));
+            if (h->r_strm) H_HIP(h, hipStreamSynchronize(h->r_strm));
             H_HIP(h, hipFree(s.d));
             s.d = nullptr;
         }
@@ -345,11 +364,6 @@ int gip_create(int device, gip_handle* out)
     gip_processor* h = new (std::nothrow) gip_processor();
     if (!h) return GIP_ERR_HIP;
     h->device = device;
-    if (hipStreamCreateWithFlags(&h->l_strm, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->r_strm, hipStreamNonBlocking) != hipSuccess) {
-        delete h;
-        return GIP_ERR_HIP;
-    }
     gip_bm_params& p = h->params;
     p.prefilter_type = GIP_PREFILTER_XSOBEL;
     p.prefilter_size = 5;
@@ -537,11 +551,7 @@ int gip_handle_clone(gip_handle src, gip_handle* out)
     h->maps_owned = false;
     h->map_w = src->map_w;
     h->map_h = src->map_h;
-    // A clone only ever runs gip_batch_run on the caller's streams: give its two side streams back.  The runtime multiplexes all streams
-    // of a process onto a handful of hardware queues; streams that share a queue serialise, so idle streams are not free (gip_streamer.cpp).
-    (void)hipStreamDestroy(h->l_strm);
-    (void)hipStreamDestroy(h->r_strm);
-    h->l_strm = h->r_strm = nullptr;
+    // (a clone only ever runs gip_batch_run on the caller's streams: its side streams are never created, stream_of)
     *out = h;
     return GIP_OK;
 }
@@ -1053,8 +1063,8 @@ int gip_clean_senders(gip_handle h)
     // a sender's payload may still be the target of an in-flight copy: drain first (the reference relies on
     // waitForAllStreams() before cleanSenders(), StereoProcessor.cpp:284-285)
     H_HIP(h, hipSetDevice(h->device));
-    H_HIP(h, hipStreamSynchronize(h->l_strm));
-    H_HIP(h, hipStreamSynchronize(h->r_strm));
+    if (h->l_strm) H_HIP(h, hipStreamSynchronize(h->l_strm));
+    if (h->r_strm) H_HIP(h, hipStreamSynchronize(h->r_strm));
     for (auto& s : h->senders)
         if (s->host) h->pinned_pool.emplace_back(s->host, s->host_bytes);
     h->senders.clear();
@@ -1074,8 +1084,8 @@ int gip_wait_for_all_streams(gip_handle h)
 {
     H_CHECK(h);
     H_HIP(h, hipSetDevice(h->device));
-    H_HIP(h, hipStreamSynchronize(h->l_strm));
-    H_HIP(h, hipStreamSynchronize(h->r_strm));
+    if (h->l_strm) H_HIP(h, hipStreamSynchronize(h->l_strm));
+    if (h->r_strm) H_HIP(h, hipStreamSynchronize(h->r_strm));
     return GIP_OK;
 }
 
@@ -1230,6 +1240,13 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     if (rc != GIP_OK) return fail(h, rc, "batch_run: StereoBM parameter validation failed");
     gip_bm_params bp = h->params;
     bp.speckle_window_size = 0;  // the node-level speckle filter below is the one the reference runs
+    // gip_batch_desc::phase: FRONT enqueues everything up to and including the matcher (which, on a matcher stream of its own, is NOT joined
+    // back), BACK waits for that matcher and enqueues the rest.  The pointer arithmetic below runs in both; `front` / `back` gate the launches.
+    const int phase = d->phase;
+    if (phase < GIP_BATCH_WHOLE || phase > GIP_BATCH_BACK) return fail(h, GIP_ERR_INVALID_ARG, "batch_run: bad phase");
+    if (phase == GIP_BATCH_BACK && !h->front_pending) return fail(h, GIP_ERR_INVALID_ARG, "batch_run: BACK phase without a FRONT phase before it");
+    if (phase != GIP_BATCH_BACK && h->front_pending) return fail(h, GIP_ERR_INVALID_ARG, "batch_run: the FRONT phase of the previous batch has not been completed by its BACK phase");
+    const bool front = phase != GIP_BATCH_BACK, back = phase != GIP_BATCH_FRONT;
 #define B_STEP(expr, what) do { rc = (expr); if (rc != GIP_OK) return propagate(h, rc, what); } while (0)
     if (h->timing_runs >= 4096) h->timing_runs = 0;  // ring: the caller is expected to read/reset well before this
     while ((int)h->tev.size() < 5 * (h->timing_runs + 1)) {
@@ -1238,7 +1255,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         h->tev.push_back(e);
     }
     hipEvent_t* ev = &h->tev[5 * h->timing_runs];
-    H_HIP(h, hipEventRecord(ev[2], st));
+    if (front) H_HIP(h, hipEventRecord(ev[2], st));
     // stage 1: colour (StereoProcessor.cpp:183-217)
     const uint8_t* mono[2] = {d->left_raw, d->right_raw};
     const uint8_t* color_l = nullptr;
@@ -1246,6 +1263,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         for (int i = 0; i < 2; i++) {
             B_STEP(ensure_dev(h, h->b_mono[i], npx * B), "batch buffers");
             const uint8_t* src = i == 0 ? d->left_raw : d->right_raw;
+            if (!front) { mono[i] = (const uint8_t*)h->b_mono[i].p; continue; }
             if (enc == 1 || enc == 2) B_STEP(gipk_cvt_bgr_to_gray(src, (size_t)w * 3, (uint8_t*)h->b_mono[i].p, w, w, hh, enc == 2, B, npx * 3, npx, st), "bgr->gray");
             else B_STEP(gipk_cvt_bayer_to_gray(src, w, (uint8_t*)h->b_mono[i].p, w, w, hh, enc - 3, B, npx, npx, st), "bayer->gray");
             mono[i] = (const uint8_t*)h->b_mono[i].p;
@@ -1254,7 +1272,8 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
             if (enc == 1) color_l = d->left_raw;
             else {
                 B_STEP(ensure_dev(h, h->b_color, npx * 3 * B), "batch buffers");
-                if (enc == 2) B_STEP(gipk_cvt_swap_rb(d->left_raw, (size_t)w * 3, (uint8_t*)h->b_color.p, (size_t)w * 3, w, hh, B, npx * 3, npx * 3, st), "rgb->bgr");
+                if (!front) {}
+                else if (enc == 2) B_STEP(gipk_cvt_swap_rb(d->left_raw, (size_t)w * 3, (uint8_t*)h->b_color.p, (size_t)w * 3, w, hh, B, npx * 3, npx * 3, st), "rgb->bgr");
                 else B_STEP(gipk_cvt_bayer_to_bgr(d->left_raw, w, (uint8_t*)h->b_color.p, (size_t)w * 3, w, hh, enc - 3, B, npx, npx * 3, st), "bayer->bgr");
                 color_l = (const uint8_t*)h->b_color.p;
             }
@@ -1277,6 +1296,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         const bool need_rect = i == 0 && need_rect_l;
         fused[i] = cam.distorted && bp.prefilter_type == GIP_PREFILTER_XSOBEL && d->fused_front_end;
         if (need_rect || !fused[i]) B_STEP(ensure_dev(h, h->b_rect[i], rplane * B), "batch buffers");
+        if (!front) continue;
         if (fused[i])
             B_STEP(gipk_rectify_xsobel(mono[i], w, w, hh, pf[i], pfp, need_rect ? (uint8_t*)h->b_rect[i].p : nullptr, rp, w, hh, h->d_map1[i], h->d_map2[i], bp.prefilter_cap, B, npx,
                                        pfplane, rplane, st), "rectify + prefilter");
@@ -1292,7 +1312,8 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     if (want_pc) {
         if (color_l) {
             B_STEP(ensure_dev(h, h->b_rect_color, npx * 3 * B), "batch buffers");
-            if (h->model.left.distorted)
+            if (!front) {}
+            else if (h->model.left.distorted)
                 B_STEP(gipk_remap_u8(color_l, (size_t)w * 3, w, hh, (uint8_t*)h->b_rect_color.p, (size_t)w * 3, w, hh, 3, h->d_map1[0], h->d_map2[0], B, npx * 3, npx * 3, st), "rectify colour");
             else
                 H_HIP(h, hipMemcpyAsync(h->b_rect_color.p, color_l, npx * 3 * B, hipMemcpyDeviceToDevice, st));
@@ -1311,6 +1332,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
     mctx.ev0 = ev[0];
     mctx.ev1 = ev[1];
     mctx.co_scheduled = d->batches_in_flight > 1 || (d->matcher_stream && (hipStream_t)d->matcher_stream != st);
+    mctx.defer_join = phase == GIP_BATCH_FRONT;
     if (d->matcher_stream && (hipStream_t)d->matcher_stream != st) {
         if (!h->match_fork) {
             H_HIP(h, hipEventCreateWithFlags(&h->match_fork, hipEventDisableTiming));
@@ -1321,8 +1343,18 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         mctx.join = h->match_join;
     }
     // both prefiltered planes are in the scratch already (null inputs)
-    rc = gip_stereobm_impl(nullptr, nullptr, pfp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, pfplane, npx * 2, st, &mctx);
+    if (phase == GIP_BATCH_BACK && h->front_join) H_HIP(h, hipStreamWaitEvent(st, h->front_join, 0));
+    if (front) h->front_cost_u16 = 1;
+    rc = gip_stereobm_phase_impl(nullptr, nullptr, pfp, w, hh, &bp, d->disparity, (size_t)w * 2, h->bm_scratch.p, h->bm_scratch.cap, B, pfplane, npx * 2, st, &mctx, phase,
+                                 &h->front_cost_u16);
     if (rc != GIP_OK) return propagate(h, rc, "stereobm");
+    if (phase == GIP_BATCH_FRONT) {
+        h->front_pending = true;
+        h->front_join = mctx.pending_join;   // null when the matcher ran on `st` itself
+        return GIP_OK;
+    }
+    h->front_pending = false;
+    (void)back;
     H_HIP(h, hipEventRecord(ev[4], st));   // end of the "remap + SAD" span: colour, rectify, prefilter, matcher, validateDisparity
     if (h->max_speckle_size > 0) {
         B_STEP(ensure_dev(h, h->spk_scratch, gipk_speckle_scratch_bytes(w, hh, B)), "batch buffers");

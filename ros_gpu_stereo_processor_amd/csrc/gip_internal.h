@@ -68,6 +68,9 @@ int gip_bm_finalize_impl(int16_t* disp, size_t disp_pitch, const void* cost, siz
 // rectify + XSOBEL front end of gip_batch_run does that.
 int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx);
+int gip_stereobm_phase_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
+                            void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx,
+                            int phase, int* cost_u16_io);
 // prefiltered planes inside a gipk_stereobm scratch buffer: pitch, per-image plane size, and the two base pointers
 void gip_stereobm_planes(void* scratch, int w, int h, int batch, uint8_t** left_f, uint8_t** right_f, size_t* pitch, size_t* plane);
 

@@ -367,10 +367,22 @@ int gip_streamer_open(gip_handle h, const gip_streamer_config* cfg, gip_streamer
     auto fail = [&](int code) { free_all(s); delete s; return code; };
     s->device = gip_device(h);
     if (hipSetDevice(s->device) != hipSuccess) return fail(GIP_ERR_HIP);
-    // Creation ORDER matters: copy-in, compute, copy-out.  With the two copy streams created back to back the runtime put their transfers on
-    // the same DMA engine and H2D and D2H no longer overlapped (27.4 k -> 18.1 k pairs/s at 64 pairs per launch, same box, same library otherwise).
-    if (hipStreamCreateWithFlags(&s->s_in, hipStreamNonBlocking) != hipSuccess) return fail(GIP_ERR_HIP);
-    s->lanes.resize(nlanes);
+    // Copy-in, compute lane(s), copy-out (and the lanes' shared matcher stream) must run side by side: with the two copy streams on one hardware
+    // queue H2D and D2H no longer overlap (27.4 k -> 18.1 k pairs/s at 64 pairs per launch, same box, same library otherwise -- and which queue a
+    // stream gets depends on every stream the process created before).  So the set is measured, not assumed (gip_concurrent_streams_create); beyond
+    // the runtime's four hardware queues the surplus streams are ordinary ones -- the matcher stream first in line, then the copies, then the lanes.
+    {
+        const int nst = 2 + nlanes + (nlanes > 1 ? 1 : 0);
+        std::vector<gip_stream> set(nst, nullptr);
+        int rc = gip_concurrent_streams_create(s->device, nst, set.data(), nullptr);
+        if (rc != GIP_OK) return fail(rc);
+        int k = 0;
+        if (nlanes > 1) s->s_match = (hipStream_t)set[k++];
+        s->s_in = (hipStream_t)set[k++];
+        s->s_out = (hipStream_t)set[k++];
+        s->lanes.resize(nlanes);
+        for (int i = 0; i < nlanes; i++) s->lanes[i].st = (hipStream_t)set[k++];
+    }
     for (int i = 0; i < nlanes; i++) {
         Lane& l = s->lanes[i];
         if (i == 0) l.h = h;
@@ -379,10 +391,7 @@ int gip_streamer_open(gip_handle h, const gip_streamer_config* cfg, gip_streamer
             if (rc != GIP_OK) return fail(rc);
             l.owned = true;
         }
-        if (hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) return fail(GIP_ERR_HIP);
     }
-    if (hipStreamCreateWithFlags(&s->s_out, hipStreamNonBlocking) != hipSuccess) return fail(GIP_ERR_HIP);
-    if (nlanes > 1 && hipStreamCreateWithFlags(&s->s_match, hipStreamNonBlocking) != hipSuccess) return fail(GIP_ERR_HIP);
     s->slots.resize(depth);
     int idx = 0;
     for (Slot& sl : s->slots) {

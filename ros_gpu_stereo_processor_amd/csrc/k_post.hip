@@ -1301,6 +1301,16 @@ void gip_stereobm_planes(void* scratch, int w, int h, int batch, uint8_t** left_
 int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
                       void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx)
 {
+    int cost_u16 = 1;
+    return gip_stereobm_phase_impl(left, right, pitch, w, h, p, disp, disp_pitch, scratch, scratch_bytes, batch, img_bstride, disp_bstride, stream, ctx, 0, &cost_u16);
+}
+
+// phase 0: everything; 1: prefilter + matcher only (*cost_u16 tells phase 2 the type of the min-SAD plane); 2: validateDisparity (+ the
+// matcher's own speckle window) only.  gip_batch_run's FRONT / BACK halves are phases 1 and 2.
+int gip_stereobm_phase_impl(const uint8_t* left, const uint8_t* right, size_t pitch, int w, int h, const gip_bm_params* p, int16_t* disp, size_t disp_pitch,
+                            void* scratch, size_t scratch_bytes, int batch, size_t img_bstride, size_t disp_bstride, gip_stream stream, const BmLaunchCtx* ctx,
+                            int phase, int* cost_u16_io)
+{
     const bool prefiltered = !left && !right;
     GIPK_ARGCHECK((prefiltered || (left && right)) && disp && scratch && p && w > 0 && h > 0 && batch > 0);
     int rc = gip_validate_bm_params(p, w, h);
@@ -1312,7 +1322,7 @@ int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     uint8_t* rf = lf + plane * batch;
     int32_t* cost = (int32_t*)gip_align_up((size_t)(uintptr_t)(rf + plane * batch), 256);
     void* spk = (void*)gip_align_up((size_t)(uintptr_t)((uint8_t*)cost + (size_t)w * h * batch * 4), 256);
-    if (!prefiltered) {
+    if (!prefiltered && phase != 2) {
         rc = gipk_prefilter(left, pitch, lf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
         if (rc != GIP_OK) return rc;
         rc = gipk_prefilter(right, pitch, rf, pp, w, h, p->prefilter_type, p->prefilter_size, p->prefilter_cap, batch, img_bstride, plane, stream);
@@ -1321,9 +1331,13 @@ int gip_stereobm_impl(const uint8_t* left, const uint8_t* right, size_t pitch, i
     const bool lr = p->disp12_max_diff >= 0;
     // min-SAD plane for the L/R check: uint16 when the column-sum matcher runs (its sums are < 65535), else int32; the byte pitch is
     // the same (rows of 4 * w bytes, half used by a uint16 plane), so the scratch layout does not depend on the choice
-    int cost_u16 = 1;
-    rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true, ctx, &cost_u16);
-    if (rc != GIP_OK) return rc;
+    int cost_u16 = *cost_u16_io;
+    if (phase != 2) {
+        rc = gip_bm_match_impl(lf, rf, pp, w, h, p, disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, batch, plane, disp_bstride, (size_t)w * h * 4, stream, true, ctx, &cost_u16);
+        if (rc != GIP_OK) return rc;
+        *cost_u16_io = cost_u16;
+        if (phase == 1) return GIP_OK;
+    }
     rc = gip_bm_finalize_impl(disp, disp_pitch, lr ? cost : nullptr, (size_t)w * 4, w, h, p, batch, disp_bstride, (size_t)w * h * 4, stream, cost_u16 != 0);
     if (rc != GIP_OK) return rc;
     if (p->speckle_range >= 0 && p->speckle_window_size > 0)

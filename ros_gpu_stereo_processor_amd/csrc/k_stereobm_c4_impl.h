@@ -962,7 +962,10 @@ int launch_c4_rf(const BmArgs& a, int batch_images, hipStream_t st, const BmLaun
     if (ev_start || ev_stop) hipExtLaunchKernelGGL((k_bm_c4<NG, R, NW, RF, NSUB>), grid, dim3(64 * NW), sh, ks, ev_start, ev_stop, 0, b);
     else hipLaunchKernelGGL((k_bm_c4<NG, R, NW, RF, NSUB>), grid, dim3(64 * NW), sh, ks, b);
     GIP_LAUNCH_CHECK();
-    if (forked) GIP_HIP_CHECK(hipStreamWaitEvent(st, ev_stop, 0));
+    if (forked) {
+        if (ctx->defer_join) ctx->pending_join = ev_stop;
+        else GIP_HIP_CHECK(hipStreamWaitEvent(st, ev_stop, 0));
+    }
     return GIP_OK;
 }
 

@@ -51,9 +51,10 @@ class BatchPipeline:
         self._maps = maps  # keep alive
         capi.check(self._lib.gip_batch_set_maps_device(self.proc.handle, self.w, self.h, *[m.data_ptr() for m in maps]), self.proc.handle)
 
-    def run(self, left_raw, right_raw, matcher_stream=None):
+    def run(self, left_raw, right_raw, matcher_stream=None, phase=capi.BATCH_WHOLE):
         """left_raw/right_raw: (B,H,W) or (B,H,W,3) uint8 CUDA tensors.  Asynchronous on torch's current stream.
-        matcher_stream: optional torch.cuda.Stream shared by all pipelines of the process for the SAD matcher kernel."""
+        matcher_stream: optional torch.cuda.Stream shared by all pipelines of the process for the SAD matcher kernel.
+        phase: capi.BATCH_FRONT / BATCH_BACK split the chain at the matcher (gip_batch_desc::phase) for two-stream software pipelining."""
         assert left_raw.is_cuda and left_raw.is_contiguous() and right_raw.is_contiguous() and left_raw.shape[0] == self.batch
         d = capi.BatchDesc()
         d.width, d.height, d.batch = self.w, self.h, self.batch
@@ -66,6 +67,7 @@ class BatchPipeline:
         d.matcher_stream = matcher_stream.cuda_stream if matcher_stream is not None else None
         d.fused_front_end = 1 if self.fused_front_end else 0
         d.batches_in_flight = int(self.batches_in_flight)
+        d.phase = int(phase)
         capi.check(self._lib.gip_batch_run(self.proc.handle, C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.proc.handle)
 
     def timing_reset(self):

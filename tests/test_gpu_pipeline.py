@@ -139,6 +139,73 @@ def test_pipelines_in_flight_with_shared_matcher_stream(gpu, block):
         p.close()
 
 
+def test_concurrent_stream_set_and_front_back_phases(gpu):
+    """gip_concurrent_streams_create hands out streams that were measured to dispatch side by side (at least the copy-in / compute / copy-out
+    trio of the streamer; four with the runtime's default four hardware queues), and gip_batch_desc::phase splits the chain at the matcher:
+    FRONT(k+1) enqueued before BACK(k) on ONE stream, the matchers on a second one -- the result must be what every pipeline produces alone.
+    Also the misuse cases: BACK without FRONT, FRONT twice, bad arguments."""
+    import ctypes as C
+    import torch
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+    lib = capi.lib()
+    arr = (C.c_void_p * 4)()
+    assert lib.gip_concurrent_streams_create(0, 0, arr, None) == 1 and lib.gip_concurrent_streams_create(0, 17, arr, None) == 1
+    assert lib.gip_concurrent_streams_create(0, 2, None, None) == 1 and lib.gip_concurrent_streams_create(99, 2, arr, None) == 5
+    idle = [torch.cuda.Stream(device=gpu) for _ in range(3)]      # streams created before must not matter
+    handles, independent = capi.concurrent_streams(4, 0)
+    assert len(set(handles)) == 4 and all(handles) and 3 <= independent <= 4
+    handles6, independent6 = capi.concurrent_streams(6, 0)        # more than the hardware queues: still six usable streams
+    assert len(set(handles6)) == 6 and 1 <= independent6 <= 6
+    capi.release_streams(handles6, 0)
+    st, shared = torch.cuda.ExternalStream(handles[0], device=gpu), torch.cuda.ExternalStream(handles[1], device=gpu)
+    w, h, nd, B = 480, 160, 64, 3
+    calib = synth.scaled_calibration(w, h)
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=9, min_disparity=0, num_disparities=nd, texture_threshold=10,
+              uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    pipes = [BatchPipeline(w, h, calib, capi.BMParams(**kw), B, "mono8", capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 0, 200, 4.0) for _ in range(2)]
+    ins = []
+    for k, p in enumerate(pipes):
+        p.install_maps(p.host_maps_to_device())
+        raws = [synth.raw_pair(w, h, nd, seed=700 + 10 * k + i, calib=calib) for i in range(B)]
+        ins.append((torch.from_numpy(np.stack([r[0] for r in raws])).to(gpu), torch.from_numpy(np.stack([r[1] for r in raws])).to(gpu)))
+    alone = []
+    for p, (l, r) in zip(pipes, ins):
+        p.run(l, r)
+        torch.cuda.synchronize()
+        alone.append((p.disparity.clone(), p.disparity_f32.clone(), p.pointcloud.clone()))
+        p.disparity.zero_(); p.disparity_f32.zero_(); p.pointcloud.zero_()
+    torch.cuda.synchronize()
+    with pytest.raises(capi.GipError):
+        pipes[0].run(*ins[0], shared, phase=capi.BATCH_BACK)                  # nothing to complete
+    n = 7
+    with torch.cuda.stream(st):
+        pipes[0].run(*ins[0], shared, phase=capi.BATCH_FRONT)
+        with pytest.raises(capi.GipError):
+            pipes[0].run(*ins[0], shared, phase=capi.BATCH_FRONT)             # the previous FRONT is still open
+        with pytest.raises(capi.GipError):
+            pipes[0].run(*ins[0], shared)                                     # ... also for a whole run
+        for i in range(n):
+            if i + 1 < n:
+                pipes[(i + 1) % 2].run(*ins[(i + 1) % 2], shared, phase=capi.BATCH_FRONT)
+            pipes[i % 2].run(*ins[i % 2], shared, phase=capi.BATCH_BACK)
+    torch.cuda.synchronize()
+    for k, p in enumerate(pipes):
+        assert torch.equal(p.disparity, alone[k][0]), k
+        assert torch.equal(p.disparity_f32, alone[k][1]), k
+        assert torch.equal(p.pointcloud.view(torch.int32), alone[k][2].view(torch.int32)), k
+    # phases on the caller's own stream (no matcher stream): FRONT then BACK is the whole chain
+    pipes[0].disparity.zero_()
+    pipes[0].run(*ins[0], phase=capi.BATCH_FRONT)
+    pipes[0].run(*ins[0], phase=capi.BATCH_BACK)
+    torch.cuda.synchronize()
+    assert torch.equal(pipes[0].disparity, alone[0][0])
+    for p in pipes:
+        p.close()
+    del st, shared, idle
+    capi.release_streams(handles, 0)
+
+
 def test_config3_1080p_bayer_nd256_block21_speckle(gpu, oracle):
     """BASELINE.json configs[2]: 1920x1080 bayer_rggb8 pair, ndisp 256, block 21 + speckle filter, full chain on one GPU.
     One frame is checked bit-exactly against the oracle (a few seconds of CPU)."""
