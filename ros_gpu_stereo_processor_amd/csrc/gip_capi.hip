@@ -149,22 +149,23 @@ int propagate(gip_handle h, int rc, const char* what)
     return rc;
 }
 
-// The two side streams (GpuStereoProcessor::getStream, GPUStereoProcessor.cpp:190-200) are created on FIRST USE: the runtime multiplexes all
-// streams of a process onto a handful of hardware queues, and streams that share a queue serialise -- a handle that only ever runs
-// gip_batch_run on the caller's streams (throughput pipelines, the streamer's lanes, row-split tiles) must not park two idle streams on
-// them (measured with tools/gip_bench.cpp: three pipelines + a matcher stream next to six idle side streams 49.8 k pairs/s, without them
-// the same as bench.py).  If a stream cannot be created the null stream serves (correct, just not concurrent).
+// The two side streams (GpuStereoProcessor::getStream, GPUStereoProcessor.cpp:190-200) are created on FIRST USE, and as a pair that was measured
+// to run side by side (gip_concurrent_streams_create): the runtime multiplexes all streams of a process onto a handful of hardware queues, and
+// streams that share a queue serialise.  A handle that only ever runs gip_batch_run on the caller's streams (throughput pipelines, the streamer's
+// lanes, row-split tiles) therefore never parks two idle streams on those queues.  If the pair cannot be created the null stream serves
+// (correct, just not concurrent).
 hipStream_t stream_of(gip_handle h, int slot_or_side)
 {
-    hipStream_t& s = (slot_or_side & GIP_SIDE_L) ? h->l_strm : h->r_strm;
-    if (!s) {
-        (void)hipSetDevice(h->device);
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    if (!h->l_strm && !h->r_strm) {
+        gip_stream pair[2] = {nullptr, nullptr};
+        if (gip_concurrent_streams_create(h->device, 2, pair, nullptr) == GIP_OK) {
+            h->l_strm = (hipStream_t)pair[0];
+            h->r_strm = (hipStream_t)pair[1];
+        } else {
             (void)hipGetLastError();
-            s = nullptr;
         }
     }
-    return s;
+    return (slot_or_side & GIP_SIDE_L) ? h->l_strm : h->r_strm;
 }
 
 int ensure_dev(gip_handle h, DevBuf& b, size_t bytes)

@@ -27,6 +27,12 @@ def test_cpp_mirror_classes(gpu, oracle, kitchen, calib, calib_files, tmp_path):
     run(cmake, "--build", str(build), "-j", jobs)
     run(cmake, "--install", str(build), "--prefix", str(prefix))
     assert (prefix / "lib" / "cmake" / "gpuimageproc_hip" / "gpuimageproc_hipConfig.cmake").exists() and (prefix / "include" / "gpuimageproc_hip.h").exists()
+    # the C++ throughput harness (tools/gip_bench.cpp: C-ABI + HIP runtime only, no Python in the loop) builds with the package and runs
+    import json
+    gb = subprocess.run([str(build / "gip_bench"), "--batch", "4", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=300)
+    assert gb.returncode == 0, gb.stdout + gb.stderr
+    line = json.loads(gb.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0 and line["pairs_per_step"] == 4 and line["independent_streams"] >= 3 and line["valid_fraction_first_image"] > 0.1
     run(cmake, "-S", os.path.join(ROOT, "tests", "cpp", "consumer"), "-B", str(cbuild), "-DCMAKE_PREFIX_PATH=%s;/opt/rocm" % prefix)
     run(cmake, "--build", str(cbuild), "-j", jobs)
     exe = cbuild / "test_processor"

@@ -2,9 +2,14 @@
 // the HIP runtime for device memory and streams.  What a C++ integrator (the reference's nodelet is C++: src/StereoProcessor.cpp) links against.
 //
 //   gip_bench [--width 1242] [--height 375] [--ndisp 128] [--block 9] [--batch 64] [--depth 3] [--steps 200] [--warmup 10]
+//             [--streams 2]            two streams in all: FRONT(k+1) / BACK(k) phases of gip_batch_run in order on one, the matchers on the other
+//   stream-mapping experiments (profiles/r03_stream_mapping.txt):
+//             [--plain-streams 1]      hipStreamCreate in program order instead of gip_concurrent_streams_create
+//             [--idle-before N] [--idle-between N] [--matcher-last 1] [--matcher-priority P] [--pipe-priority P]   (with --plain-streams 1)
 //
 // `depth` processor handles, each with its own stream and output buffers, take the steps in turn; the SAD matchers of all of them go to ONE
-// shared stream (gip_batch_desc::matcher_stream), exactly as bench.py does.  Inputs are synthetic (textured noise with planted disparities,
+// shared stream (gip_batch_desc::matcher_stream), exactly as bench.py does.  The streams come as one set measured to dispatch side by side
+// (gip_concurrent_streams_create).  Inputs are synthetic (textured noise with planted disparities,
 // resident in HBM before the timed region); the calibration is the reference fixture's left camera (test/stereobm/test_data/left.yaml) scaled
 // to the image size.  Prints one JSON line.  Results are not checked here -- parity lives in tests/ (this binary never links the oracle).
 #include <hip/hip_runtime.h>
