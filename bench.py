@@ -634,16 +634,20 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
         # the batch streams and the matcher stream as ONE set of streams that were measured to dispatch side by side (gip_concurrent_streams_create):
         # which hardware queue a HIP stream lands on depends on every stream the process created before, and a matcher stream that shares a
         # queue with a batch stream costs 12-25 %
-        handles, independent_streams = capi.concurrent_streams(len(pipes) + (1 if want_matcher else 0), local_rank)
+        two = args.matcher_stream == "two" and len(pipes) > 1
+        handles, independent_streams = capi.concurrent_streams(len(pipes) + (2 if two else 1 if want_matcher else 0), local_rank)
         ext = [torch.cuda.ExternalStream(hd, device=dev) for hd in handles]
-        streams, matcher_stream = ext[:len(pipes)], (ext[len(pipes)] if want_matcher else None)
+        streams, matcher_stream = ext[:len(pipes)], (ext[len(pipes)] if (want_matcher or two) else None)
     else:
         matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if want_matcher else None
     # "two": two matcher streams taken in turn, so that the ragged end of one matcher launch overlaps the start of the next
     matcher_streams = [matcher_stream]
     if args.matcher_stream == "two" and len(pipes) > 1:
-        matcher_stream = torch.cuda.Stream(device=dev)
-        matcher_streams = [matcher_stream, torch.cuda.Stream(device=dev)]
+        if independent_streams is not None:
+            matcher_streams = [ext[len(pipes)], ext[len(pipes) + 1]]
+        else:
+            matcher_stream = torch.cuda.Stream(device=dev)
+            matcher_streams = [matcher_stream, torch.cuda.Stream(device=dev)]
     for p in pipes:
         p.install_maps(maps)
 
