@@ -56,7 +56,10 @@ VALU_PEAK_LANE_SLOTS = 39.3e12   # measured VOP3 issue rate, tools/ubench_valu.h
 def bm_kwargs():
     # cv::StereoBM defaults (XSOBEL, cap 31, texture 10, uniqueness 15) + the L/R consistency check north_star asks for
     return dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=BLOCK, min_disparity=0, num_disparities=NDISP,
-                texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+                texture_threshold=10, uniqueness_ratio=15, disp12_max_diff=DISP12, speckle_window_size=0, speckle_range=0)
+
+
+DISP12 = 1      # --ablate lr (experiment) sets -1: no L/R consistency check
 
 
 SPECKLE_SIZE, SPECKLE_DIFF = 800, 5.0  # cfg/GPU.cfg:34-35 defaults
@@ -508,6 +511,7 @@ def main():
     ap.add_argument("--plain-streams", action="store_true", help="EXPERIMENT: create the pipeline's streams with torch.cuda.Stream in program order instead of gip_concurrent_streams_create")
     ap.add_argument("--chain-priority", type=int, default=0, help="HIP stream priority of the per-batch streams that carry everything but the matcher (-1 = high)")
     ap.add_argument("--matcher-priority", type=int, default=0, help="HIP stream priority of the shared matcher stream (negative = higher).  Measured: -1 starves the kernels that feed the matcher, 41.8 k against 53.4 k pairs/s at 0")
+    ap.add_argument("--ablate", default="", help="experiment (NOT the metric's configuration; implies --no-verify): comma list of stages to leave out -- speckle, f32 (with --no-cloud: no output kernel at all), lr (no L/R check)")
     ap.add_argument("--no-cloud", action="store_true", help="experiment (NOT the metric's configuration): float disparity only, no PointCloud2 records")
     ap.add_argument("--chain-cu-mask", default="", help="experiment: PATTERN/PERIOD, e.g. 0x1/4 = the per-batch (non-matcher) streams may use every fourth CU only")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency probe (keeps kernel profiles clean)")
@@ -604,9 +608,15 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
     # precision) and broadcasts both once over RCCL (xGMI); the other ranks run on exactly those tables.  Frames are
     # independent units (frame i -> rank i mod N, dist.frame_shard), so no collective follows on the data path.
     calib, maps = gdist.broadcast_model(calib0 if rank == 0 else None, W, H, dev)
+    ablate = set(x for x in args.ablate.split(",") if x)
+    if ablate:
+        args.no_verify = True
+    if "lr" in ablate:
+        global DISP12
+        DISP12 = -1
     params = capi.BMParams(**bm_kwargs())
     outputs = capi.TOPIC_DISPARITY | (0 if args.no_cloud else capi.TOPIC_POINTCLOUD)
-    pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, SPECKLE_SIZE, SPECKLE_DIFF, want_f32=True, fused_front_end=args.fused_front_end, batches_in_flight=max(1, depth))
+    pipes = [BatchPipeline(W, H, calib, params, B, ENCODING, outputs, local_rank, 0 if "speckle" in ablate else SPECKLE_SIZE, SPECKLE_DIFF, want_f32="f32" not in ablate, fused_front_end=args.fused_front_end, batches_in_flight=max(1, depth))
              for _ in range(max(1, depth))]
     if args.chain_cu_mask:
         # experiment: the per-batch streams (everything but the matcher) restricted to a subset of the CUs (hipExtStreamCreateWithCUMask), so that the
@@ -760,7 +770,7 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt_max / steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"] + (" [EXPERIMENT: no PointCloud2 output]" if args.no_cloud else ""), "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "independent_streams": independent_streams, "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
+            "config": {"workload": wl["name"] + (" [EXPERIMENT: no PointCloud2 output]" if args.no_cloud else "") + (" [EXPERIMENT: without %s]" % args.ablate if args.ablate else ""), "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "independent_streams": independent_streams, "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
                        "parallelism": "frame-sharded x%d: frame g of a %d-frame bag -> rank g mod %d" % (world, BAG_FRAMES, world)},
             "verified": verified,
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
