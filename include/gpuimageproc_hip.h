@@ -476,7 +476,7 @@ typedef struct gip_batch_desc {
                                 * a pipeline otherwise.  Setting matcher_stream implies > 1 */
     int32_t phase;             /* GIP_BATCH_WHOLE (0, default): the whole chain.  GIP_BATCH_FRONT: colour, rectify, prefilter and the matcher
                                 * only -- with a matcher_stream the matcher is launched there and `stream` does NOT wait for it.
-                                * GIP_BATCH_BACK (same handle, same descriptor, after its FRONT): wait for that matcher, then L/R check,
+                                * GIP_BATCH_BACK (same handle, same descriptor and same `stream`, after its FRONT): wait for that matcher, then L/R check,
                                 * speckle filter and the outputs.  A host that enqueues FRONT(k+1) before BACK(k) software-pipelines the
                                 * batches on TWO streams in all: the matchers back to back on matcher_stream, everything else in order on
                                 * `stream` next to them (handles and buffers: three sets in rotation).  See DESIGN.md section 4 */

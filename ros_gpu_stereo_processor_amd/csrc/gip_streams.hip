@@ -73,13 +73,20 @@ int gip_concurrent_streams_create(int device, int n, gip_stream* streams, int* n
     GIP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     pr.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     GIP_HIP_CHECK(hipMalloc((void**)&pr.d, 4096));
+    if (hipMemset(pr.d, 0, 4096) != hipSuccess) {
+        (void)hipFree(pr.d);
+        return GIP_ERR_HIP;
+    }
     std::vector<hipStream_t> kept, spare;
     int rc = GIP_OK;
     auto make = [&](hipStream_t* s) -> int {
         GIP_HIP_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
         hipLaunchKernelGGL(k_probe_touch, dim3(1), dim3(64), 0, *s, pr.d + 64);    // the first launch sets the stream's queue up
-        GIP_LAUNCH_CHECK();
-        GIP_HIP_CHECK(hipStreamSynchronize(*s));
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(*s) != hipSuccess) {
+            (void)hipStreamDestroy(*s);
+            *s = nullptr;
+            return GIP_ERR_HIP;
+        }
         return GIP_OK;
     };
     // rejected candidates stay alive until the end: the runtime hands a new stream the least loaded queue, so they steer the next
@@ -90,7 +97,7 @@ int gip_concurrent_streams_create(int device, int n, gip_stream* streams, int* n
         if (rc != GIP_OK) break;
         bool clash = false;
         for (size_t i = 0; i < kept.size() && !clash && rc == GIP_OK; i++) rc = pr.conflict(kept[i], c, &clash);
-        (clash ? spare : kept).push_back(c);
+        (clash || rc != GIP_OK ? spare : kept).push_back(c);     // (on an error the candidate is released with the spares below)
     }
     const int independent = (int)kept.size();
     while (rc == GIP_OK && (int)kept.size() < n) {       // not enough independent queues (n above GPU_MAX_HW_QUEUES): fill up with what there is
