@@ -206,6 +206,42 @@ def test_concurrent_stream_set_and_front_back_phases(gpu):
     capi.release_streams(handles, 0)
 
 
+@pytest.mark.parametrize("encoding", ["bayer_rggb8", "bgr8", "rgb8"])
+def test_front_back_phases_colour_encodings(gpu, encoding):
+    """FRONT / BACK on colour inputs: the colour conversion, the rectified colour plane of the cloud and the fused front end all sit in the FRONT half;
+    BACK must find them.  Compared with the whole run of the same pipeline."""
+    import torch
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.pipeline import BatchPipeline
+    w, h, nd, B = 320, 128, 48, 2
+    calib = synth.scaled_calibration(w, h)
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=11, min_disparity=0, num_disparities=nd, texture_threshold=10,
+              uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    raws = [synth.raw_pair(w, h, nd, seed=40 + i, calib=calib)[:2] for i in range(B)]
+    if encoding.startswith("bayer"):
+        L = np.stack([synth.bayer_mosaic(synth.colorize(r[0], 1), encoding) for r in raws])
+        R = np.stack([synth.bayer_mosaic(synth.colorize(r[1], 2), encoding) for r in raws])
+    else:
+        L = np.stack([synth.colorize(r[0], 1) for r in raws])
+        R = np.stack([synth.colorize(r[1], 2) for r in raws])
+    l, r = torch.from_numpy(np.ascontiguousarray(L)).to(gpu), torch.from_numpy(np.ascontiguousarray(R)).to(gpu)
+    for fused in (False, True):
+        pipe = BatchPipeline(w, h, calib, capi.BMParams(**kw), B, encoding, capi.TOPIC_DISPARITY | capi.TOPIC_POINTCLOUD, 0, 100, 4.0, fused_front_end=fused)
+        pipe.install_maps(pipe.host_maps_to_device())
+        pipe.run(l, r)
+        torch.cuda.synchronize()
+        whole = (pipe.disparity.clone(), pipe.disparity_f32.clone(), pipe.pointcloud.clone())
+        pipe.disparity.zero_(); pipe.disparity_f32.zero_(); pipe.pointcloud.zero_()
+        shared = torch.cuda.Stream(device=gpu)
+        pipe.run(l, r, shared, phase=capi.BATCH_FRONT)
+        pipe.run(l, r, shared, phase=capi.BATCH_BACK)
+        torch.cuda.synchronize()
+        assert torch.equal(pipe.disparity, whole[0]) and torch.equal(pipe.disparity_f32, whole[1])
+        assert torch.equal(pipe.pointcloud.view(torch.int32), whole[2].view(torch.int32))
+        assert (pipe.disparity != -16).float().mean() > 0.2
+        pipe.close()
+
+
 def test_config3_1080p_bayer_nd256_block21_speckle(gpu, oracle):
     """BASELINE.json configs[2]: 1920x1080 bayer_rggb8 pair, ndisp 256, block 21 + speckle filter, full chain on one GPU.
     One frame is checked bit-exactly against the oracle (a few seconds of CPU)."""
