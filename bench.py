@@ -27,7 +27,10 @@ ENCODING = "mono8"
 # BASELINE.json configs[1] (the one `metric` is quoted on, default) and configs[2] (north_star's second size; --workload hd1080)
 WORKLOADS = {
     # depth = batches in flight per GPU, shared = their matcher kernels go to ONE stream (both measured per workload)
-    "kitti": dict(W=1242, H=375, NDISP=128, BLOCK=9, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<8,4,1>",
+    # batch: pairs resident per step.  Measured (one MI355X, gpurun_out/bsz*.log): kitti 54.1 k pairs/s at 32, 57.3 k at 64, 60.7 k at 128, 61.7 k at 256, 61.6 k at 512
+    # (the matcher's last partly filled round of workgroups and the hand-over between two matcher launches are amortised over more pairs); refdefault
+    # 69.4 / 72.5 / 73.6 k at 64 / 128 / 256; euroc and hd1080 do not move.  256 pairs are 8 GB per pipeline including the 3.8 GB of cloud records.
+    "kitti": dict(W=1242, H=375, NDISP=128, BLOCK=9, ENCODING="mono8", batch=256, depth=3, shared=True, kernel="k_bm_c4<8,4,1>",
                   name="KITTI-size 1242x375 mono8, ndisp=128 block=9, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
                        "->speckle(800,5)->f32 disparity+PointCloud2"),
     "hd1080": dict(W=1920, H=1080, NDISP=256, BLOCK=21, ENCODING="bayer_rggb8", batch=8, depth=2, shared=False, kernel="k_bm_c4<4,10,4>",
@@ -40,7 +43,7 @@ WORKLOADS = {
     "euroc": dict(W=752, H=480, NDISP=64, BLOCK=15, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<4,7,1>",
                   name="EuRoC-size 752x480 mono8, ndisp=64 block=15, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
     # the reference constructor's matcher shape, createStereoBM(48, 19) (reference src/GPUStereoProcessor.cpp:18-20), at the KITTI size
-    "refdefault": dict(W=1242, H=375, NDISP=48, BLOCK=19, ENCODING="mono8", batch=64, depth=3, shared=True, kernel="k_bm_c4<6,9,1,*,2> (two images of the batch per wave)",
+    "refdefault": dict(W=1242, H=375, NDISP=48, BLOCK=19, ENCODING="mono8", batch=256, depth=3, shared=True, kernel="k_bm_c4<6,9,1,*,2> (two images of the batch per wave)",
                        name="1242x375 mono8, ndisp=48 block=19 (the reference's createStereoBM(48, 19)), full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
                             "->speckle(800,5)->f32 disparity+PointCloud2"),
 }
@@ -489,7 +492,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti", help="kitti = BASELINE configs[1] (the metric's config); hd1080 = configs[2]; uhd4k = the frame of configs[4] on one GPU")
-    ap.add_argument("--batch", type=int, default=0, help="stereo pairs per step per GPU (default: 64 for kitti, 8 for hd1080, 1 for uhd4k)")
+    ap.add_argument("--batch", type=int, default=0, help="stereo pairs per step per GPU (default: 256 for kitti / refdefault, 64 for euroc, 8 for hd1080, 1 for uhd4k)")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight per GPU (each on its own HIP stream with its own buffers): the pre/post "
                     "kernels of one batch run under the matcher of another.  Default per workload (kitti 3, others 2)")
     ap.add_argument("--matcher-stream", choices=["auto", "shared", "two", "own"], default="auto", help="shared: the matcher kernels of all batches in flight go to "

@@ -1,7 +1,7 @@
 // gip_bench.cpp -- the throughput measurement of bench.py from a plain C++ host: no Python, no torch, only the C-ABI (gpuimageproc_hip.h) and
 // the HIP runtime for device memory and streams.  What a C++ integrator (the reference's nodelet is C++: src/StereoProcessor.cpp) links against.
 //
-//   gip_bench [--width 1242] [--height 375] [--ndisp 128] [--block 9] [--batch 64] [--depth 3] [--steps 200] [--warmup 10]
+//   gip_bench [--width 1242] [--height 375] [--ndisp 128] [--block 9] [--batch 256] [--depth 3] [--steps 200] [--warmup 10]
 //             [--streams 2]            two streams in all: FRONT(k+1) / BACK(k) phases of gip_batch_run in order on one, the matchers on the other
 //   stream-mapping experiments (profiles/r03_stream_mapping.txt):
 //             [--plain-streams 1]      hipStreamCreate in program order instead of gip_concurrent_streams_create
@@ -58,7 +58,7 @@ static void scaled_camera(int w, int h, bool right, gip_camera_info* ci)
 
 int main(int argc, char** argv)
 {
-    int w = 1242, h = 375, nd = 128, block = 9, B = 64, depth = 3, steps = 200, warmup = 10, idle_before = 0, idle_between = 0, matcher_last = 0, mprio = 0, pprio = 0, streams = 0, plain = 0;
+    int w = 1242, h = 375, nd = 128, block = 9, B = 256, depth = 3, steps = 200, warmup = 10, idle_before = 0, idle_between = 0, matcher_last = 0, mprio = 0, pprio = 0, streams = 0, plain = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
         const int v = std::atoi(argv[i + 1]);
