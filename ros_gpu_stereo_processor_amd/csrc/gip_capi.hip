@@ -1379,7 +1379,7 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
 #endif
         B_STEP(gip_disparity_outputs_impl(d->disparity, (size_t)w * 2, rect_color, rect_color_cn == 1 ? rp : (size_t)w * 3, rect_color_cn, d->disparity_f32,
                                           want_pc ? d->pointcloud : nullptr, w, hh, 0, h->model.Q, h->model.left.cx(), h->model.right.cx(), bp.min_disparity, B, npx * 2,
-                                          rect_color_cn == 1 ? rplane : npx * 3, st, tab, bp.num_disparities), "disparity outputs");
+                                          rect_color_cn == 1 ? rplane : npx * 3, st, tab, bp.num_disparities, true), "disparity outputs");
     }
     H_HIP(h, hipEventRecord(ev[3], st));
     h->timing_runs++;

@@ -80,4 +80,6 @@ size_t gip_w_table_bytes(int ndisp);
 int gip_w_table_build(void* table, const double Q[16], double cx_l, double cx_r, int min_disparity, int ndisp, gip_stream stream);
 int gip_disparity_outputs_impl(const int16_t* disp, size_t disp_pitch, const uint8_t* color, size_t color_pitch, int color_cn, float* f32_out, uint8_t* pc_out, int w, int h,
                                int y_origin, const double Q[16], double cx_l, double cx_r, int min_disparity, int batch, size_t disp_bstride, size_t color_bstride,
-                               gip_stream stream, const void* w_table, int table_ndisp);
+                               gip_stream stream, const void* w_table, int table_ndisp, bool own_disparity = false);
+// own_disparity: every value of `disp` was produced by this library's matcher (+ speckle filter) with the parameters the table was built for,
+// i.e. lies inside the table -- the table-only kernel may run (k_disp_outputs_tab)

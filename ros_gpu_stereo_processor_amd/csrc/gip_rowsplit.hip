@@ -303,7 +303,7 @@ int post_body(gip_rowsplit_s* rs, Tile& T)
             else { col = T.rect + (size_t)(T.y0 - T.e0) * 2 * rs->rp; cpitch = 2 * rs->rp; cn = 1; }   // mono input: the rectified left rows, replicated (GRAY2BGR)
         }
         RS_STEP(rs, gip_disparity_outputs_impl(d_own, (size_t)w * 2, col, cpitch, cn, T.f32, T.pc, w, hown, T.y0, T.v.Q, T.v.cx_l, T.v.cx_r, rs->bp.min_disparity, 1, 0, 0, T.st,
-                                               T.w_tab, rs->bp.num_disparities), "disparity outputs");
+                                               T.w_tab, rs->bp.num_disparities, true), "disparity outputs");
     }
     return GIP_OK;
 }
