@@ -289,8 +289,9 @@ int64_t gip_ros1_serialize_pointcloud2(const gip_pointcloud2_msg *msg, uint8_t *
  * compute of frames i and i-1 and download of frame i-2 overlap; gip_streamer_submit blocks only when every ring slot is still in flight
  * (back-pressure).
  * The caller submits pair by pair and never chooses a batch size (batching 0, the default): a pair joins the batch being filled, and that
- * batch is launched as soon as a compute lane is free (or it is full) -- batches of one pair and minimal latency for a camera, batches that
- * grow until the launch overhead is amortised for a bag replay.
+ * batch is launched as soon as a compute lane is free and no earlier batch is still on its way back to the host (or it is full) -- batches of
+ * one pair and minimal latency for a camera, full batches for a caller that saturates the host link (the copy-out is the slowest stage then, and
+ * cutting batches short would only add launches).
  * The processor handle must have its model and parameters set; it must not be used for anything else, nor have its parameters changed,
  * while a streamer is open (the other compute lanes run on clones of it made at open). */
 typedef struct gip_streamer_s *gip_streamer;
@@ -306,7 +307,8 @@ typedef struct gip_streamer_config {
                               * tight rows and stay valid until their pair has been delivered: the H2D copy then reads them in place and the
                               * submitting thread copies nothing */
     int32_t batching;        /* 0 (default): adaptive -- a partly filled batch is launched whenever fewer than compute_lanes batches are
-                              * computing; 1: fixed -- only full batches are launched (a partial one by gip_streamer_flush) */
+                              * computing and the copy-out stream is idle; 1: fixed -- only full batches are launched (a partial one by
+                              * gip_streamer_flush) */
     int32_t compute_lanes;   /* batches computing concurrently, each on its own stream and processor handle (0 -> 2; 1..4) */
 } gip_streamer_config;
 typedef struct gip_streamer_result {

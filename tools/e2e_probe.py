@@ -15,7 +15,7 @@ bench.set_workload(wl)
 from ros_gpu_stereo_processor_amd import capi  # noqa: E402
 
 lraw, rraw, calib = bench.make_inputs(8, seed0=100, nseeds=8)
-out = bench.e2e_streaming(lraw, rraw, calib, capi.BMParams(**bench.bm_kwargs()), 0, budget_s=4.0)
+out = bench.e2e_streaming(lraw, rraw, calib, capi.BMParams(**bench.bm_kwargs()), 0, budget_s=float(os.environ.get("E2E_BUDGET", "4.0")))
 print(json.dumps(out["measured_link_gbs"]))
 for r in out["records"]:
     print(json.dumps({k: r[k] for k in ("what", "batching", "max_pairs_per_launch", "compute_lanes", "avg_pairs_per_launch", "pairs_per_s", "frac_of_pcie_bound", "frac_of_measured_link")}))
