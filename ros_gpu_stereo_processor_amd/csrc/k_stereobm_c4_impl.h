@@ -428,20 +428,38 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
 #pragma unroll
         for (int q = 0; q < 4; q++) psh[q] = 8u * (u32)((clampi(c0 + 4 * t + q, rlo, rhi) - c0) & 3);
     }
-    struct PfRegs { u32 l; u32 r[NLD]; };
+    // The prefetch registers hold the RAW dword pairs: aligning, masking and biasing them is left to commit_to, one row later.  (Done at load
+    // time -- as until late in round 3 -- the very next instruction needs the data, the compiler puts s_waitcnt vmcnt(0) right behind the loads
+    // and the "prefetch" waits out the whole memory round trip every row; next to an HBM-bound kernel of another batch that is many microseconds:
+    // a 1 GiB fill looping on a second stream stretched the matcher by 44 %, tools/interfere_probe.py.)
+    struct PfRegs { u32 l_lo, l_hi; u32 r_lo[NLD], r_hi[NLD]; };
     PfRegs pfE = {}, pfS = {};        // the row entering the window next; (RF) the row leaving it next
+    const int lcol_q = lcol0 + 4 * ti;
+    const bool l_edge = !(lcol_q >= 0 && lcol_q + 3 <= a.w - 1);      // this lane's left quad straddles an image edge: fetch_l's byte path, final at once
     auto prefetch_to = [&](PfRegs& pf, int yy) {
-        if (ti < 16) pf.l = fetch_l(yy);
+        if (ti < 16) {
+            if (l_edge) pf.l_lo = fetch_l(yy);
+            else {
+                const u32* row = (const u32*)(Lb + (size_t)yy * a.pitch);
+                pf.l_lo = row[clampi(ldw, 0, ndw - 1)];
+                pf.l_hi = row[clampi(ldw + 1, 0, ndw - 1)];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (ti + NTS * i < RWD) pf.r[i] = fetch(Rb, yy, rdw + NTS * i, rsh);
+            if (ti + NTS * i < RWD) {
+                const u32* row = (const u32*)(Rb + (size_t)yy * a.pitch);
+                pf.r_lo[i] = row[clampi(rdw + NTS * i, 0, ndw - 1)];
+                pf.r_hi[i] = row[clampi(rdw + NTS * i + 1, 0, ndw - 1)];
+            }
     };
+    auto finish = [&](u32 lo, u32 hi, int sh) -> u32 { return (__builtin_amdgcn_alignbyte(hi, lo, sh) & 0x7F7F7F7Fu) + 0x01010101u; };
     auto commit_to = [&](const PfRegs& pf, int sidx) {
         u32* slot = ring + sidx * NSUB * SLOTD;
-        if (ti < 16) slot[ti] = pf.l;
+        if (ti < 16) slot[ti] = l_edge ? pf.l_lo : finish(pf.l_lo, pf.l_hi, lsh);
 #pragma unroll
         for (int i = 0; i < NLD; i++)
-            if (ti + NTS * i < RWD) slot[16 + ti + NTS * i] = pf.r[i];
+            if (ti + NTS * i < RWD) slot[16 + ti + NTS * i] = finish(pf.r_lo[i], pf.r_hi[i], rsh);
     };
     auto prefetch = [&](int yy) { prefetch_to(pfE, yy); };
     auto commit = [&](int yy) { commit_to(pfE, RF ? 0 : yy % NRING); };
@@ -580,14 +598,35 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         csw[q] = (live_lane ? cs + (size_t)(q * NLIVE + t - TLO) * CSPB : dump + 4 * doff) + (size_t)(4 * NG * s) * 2;
     });
 
-    // One iteration (row y): commit row y+R to the ring -> issue its LDS reads (A) and the global loads of row y+R+1 -> add row y+R ->
-    // window sums / WTA / parks -> merge, uniqueness, finalise, store -> subtract row y-R (the row that leaves the window).
+    // The results of a row are STORED one iteration later, right before the next row's loads are issued: the s_waitcnt vmcnt(0) in front of
+    // commit() (the prefetched row is needed there) then finds loads and stores that are a whole row old, instead of stores issued a few hundred
+    // cycles earlier whose acknowledgement it would have to sit out (gfx9 counts loads and stores in the one vmcnt).
+    bool pend_w[NFIN];
+    int pend_d[NFIN], pend_ms[NFIN];
+#pragma unroll
+    for (int jf = 0; jf < NFIN; jf++) { pend_w[jf] = false; pend_d[jf] = 0; pend_ms[jf] = 0; }
+    auto flush_row = [&](int yr) {
+#pragma unroll
+        for (int jf = 0; jf < NFIN; jf++) {
+            if (!pend_w[jf]) continue;
+            const int c_out = c0 + 4 * t + qf0 + jf;
+            disp[(size_t)yr * a.dpitch + a.lofs + c_out] = (int16_t)pend_d[jf];
+            if (cost) {
+                if (a.cost16) ((uint16_t*)cost)[(size_t)yr * a.cpitch + a.lofs + c_out] = (uint16_t)pend_ms[jf];
+                else cost[(size_t)yr * a.cpitch + a.lofs + c_out] = pend_ms[jf];
+            }
+            pend_w[jf] = false;
+        }
+    };
+    // One iteration (row y): commit row y+R to the ring -> issue its LDS reads (A), the stores of row y-1 and the global loads of row y+R+1 ->
+    // add row y+R -> window sums / WTA / parks -> merge, uniqueness, finalise -> subtract row y-R (the row that leaves the window).
     for (int y = ya; y < yb; y++) {
         wg_sync();                // every wave is done with the slot row y+R replaces
         commit(y + R);
         if constexpr (RF) commit_to(pfS, 1);        // row y-R
         wg_sync();
         const RowRegs A = RF ? read_slot(0) : read_row(y + R);
+        flush_row(y - 1);
         if (y + R + 1 < a.h) prefetch(y + R + 1);
         if constexpr (RF) prefetch_to(pfS, y - R + 1);
         add_regs(A);
@@ -805,17 +844,14 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 if (ok) d_out = v >> 4;
             }
         }
-        if (writer) {
-            disp[(size_t)y * a.dpitch + a.lofs + c_out] = (int16_t)d_out;
-            if (cost) {
-                if (a.cost16) ((uint16_t*)cost)[(size_t)y * a.cpitch + a.lofs + c_out] = (uint16_t)minsad;
-                else cost[(size_t)y * a.cpitch + a.lofs + c_out] = minsad;
-            }
-        }
+        pend_w[jf] = writer;
+        pend_d[jf] = d_out;
+        pend_ms[jf] = minsad;
         }   // the lane's pixels
         }   // finalising wave
         if (!(C4_ABLATE & 1)) sub_regs(RF ? read_slot(1) : read_row(y - R));
     }
+    flush_row(yb - 1);
 }
 
 template <int NG, int R, int NW, bool RF, int NSUB = 1>
