@@ -500,6 +500,9 @@ def main():
     ap.add_argument("--matcher-stream", choices=["auto", "shared", "two", "own"], default="auto", help="shared: the matcher kernels of all batches in flight go to "
                     "ONE stream and run back to back (kitti, depth 3: 49.2k pairs/s against 43.2k with own streams); own: every batch keeps its "
                     "matcher on its own stream (better for the large-disparity workloads)")
+    ap.add_argument("--schedule", choices=["auto", "batch", "fpm"], default="auto", help="batch: every batch in flight on a stream of its own (+ the shared matcher stream); "
+                    "fpm: THREE streams in all -- every batch's front end in order on one, every batch's L/R check + speckle + outputs in order on another, "
+                    "the matchers on the third (gip_batch_desc::phase), --depth handles in rotation")
     ap.add_argument("--fused-front-end", action="store_true", help="rectify + XSOBEL as ONE pass raw -> prefiltered plane (gipk_rectify_xsobel) instead of remap, then prefilter "
                     "(bit-identical; measured slower on MI355X, DESIGN.md 3.3)")
     ap.add_argument("--rowsplit", action="store_true", help="BASELINE configs[4] mode: ONE frame per step cut into row tiles over the ranks (halo exchange + distributed "
@@ -602,6 +605,9 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
     B = batch if batch > 0 else wl["batch"]
     depth = depth if depth > 0 else wl["depth"]
     shared_matcher = wl["shared"] if args.matcher_stream == "auto" else args.matcher_stream == "shared"
+    schedule = wl.get("schedule", "batch") if args.schedule == "auto" else args.schedule
+    if schedule == "fpm":
+        shared_matcher = True
     # BASELINE configs[3]: a synthetic bag of BAG_FRAMES stereo pairs (30 s at 30 fps), frame g -> rank g mod N (dist.frame_shard), no
     # data-path collective.  A step is one batch of B pairs PER RANK, so step i of rank r holds the bag frames
     # ((i * B + j) * N + r) mod BAG_FRAMES, j = 0..B-1: N ranks together walk the bag front to back, each on its own shard
@@ -650,9 +656,10 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
         # which hardware queue a HIP stream lands on depends on every stream the process created before, and a matcher stream that shares a
         # queue with a batch stream costs 12-25 %
         two = args.matcher_stream == "two" and len(pipes) > 1
-        handles, independent_streams = capi.concurrent_streams(len(pipes) + (2 if two else 1 if want_matcher else 0), local_rank)
+        nbatch_streams = 2 if (schedule == "fpm" and want_matcher) else len(pipes)      # fpm: one stream for the front ends, one for the back ends
+        handles, independent_streams = capi.concurrent_streams(nbatch_streams + (2 if two else 1 if want_matcher else 0), local_rank)
         ext = [torch.cuda.ExternalStream(hd, device=dev) for hd in handles]
-        streams, matcher_stream = ext[:len(pipes)], (ext[len(pipes)] if (want_matcher or two) else None)
+        streams, matcher_stream = ext[:nbatch_streams], (ext[nbatch_streams] if (want_matcher or two) else None)
     else:
         matcher_stream = torch.cuda.Stream(device=dev, priority=args.matcher_priority) if want_matcher else None
     # "two": two matcher streams taken in turn, so that the ragged end of one matcher launch overlaps the start of the next
@@ -681,9 +688,17 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
     inputs = [step_inputs(i) for i in range(ninputs)]
     left, right = inputs[0]
 
+    fpm = schedule == "fpm" and len(pipes) > 1 and matcher_stream is not None
+
     def run_step(i):
         k = i % len(pipes)
         l, r = inputs[i % len(inputs)]
+        if fpm:
+            with torch.cuda.stream(streams[0]):
+                pipes[k].run(l, r, matcher_stream, phase=capi.BATCH_FRONT)
+            with torch.cuda.stream(streams[1]):
+                pipes[k].run(l, r, matcher_stream, phase=capi.BATCH_BACK)
+            return
         with torch.cuda.stream(streams[k]):
             pipes[k].run(l, r, matcher_streams[i % len(matcher_streams)])
     torch.cuda.synchronize()
@@ -775,7 +790,7 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
             "value": round(value, 2), "unit": "stereo pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt_max / steps, 4), "ms_per_frame": round(1e3 * dt_max / (B * steps), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"] + (" [EXPERIMENT: no PointCloud2 output]" if args.no_cloud else "") + (" [EXPERIMENT: without %s]" % args.ablate if args.ablate else ""), "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "independent_streams": independent_streams, "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
+            "config": {"workload": wl["name"] + (" [EXPERIMENT: no PointCloud2 output]" if args.no_cloud else "") + (" [EXPERIMENT: without %s]" % args.ablate if args.ablate else ""), "pairs_per_step_per_gpu": B, "batches_in_flight_per_gpu": len(pipes), "schedule": ("front / back / matcher streams" if fpm else "one stream per batch"), "independent_streams": independent_streams, "matcher_stream": ("two" if len(matcher_streams) > 1 else "shared") if matcher_stream is not None else "own",
                        "parallelism": "frame-sharded x%d: frame g of a %d-frame bag -> rank g mod %d" % (world, BAG_FRAMES, world)},
             "verified": verified,
             "roofline": {"bound": "hbm", "kernel": wl["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -481,7 +481,9 @@ typedef struct gip_batch_desc {
                                 * GIP_BATCH_BACK (same handle, same descriptor and same `stream`, after its FRONT): wait for that matcher, then L/R check,
                                 * speckle filter and the outputs.  A host that enqueues FRONT(k+1) before BACK(k) software-pipelines the
                                 * batches on TWO streams in all: the matchers back to back on matcher_stream, everything else in order on
-                                * `stream` next to them (handles and buffers: three sets in rotation).  See DESIGN.md section 4 */
+                                * `stream` next to them (handles and buffers: three sets in rotation).  With a matcher_stream the BACK phase may
+                                * also run on a stream of its OWN (all FRONT phases in order on one stream, all BACK phases on another, the
+                                * matchers on the third): the handle orders its own buffers by events.  See DESIGN.md section 4 */
 } gip_batch_desc;
 enum { GIP_BATCH_WHOLE = 0, GIP_BATCH_FRONT = 1, GIP_BATCH_BACK = 2 };
 int gip_batch_set_maps_device(gip_handle h, int width, int height, const int16_t *map1_l, const uint16_t *map2_l,

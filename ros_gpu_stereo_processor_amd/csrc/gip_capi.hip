@@ -91,6 +91,8 @@ struct gip_processor {
     bool front_pending = false;                              // gip_batch_run: a FRONT phase waits for its BACK phase
     hipEvent_t front_join = nullptr;                         //   ... the matcher's completion event of that FRONT phase (one of the events above / tev)
     int front_cost_u16 = 1;                                  //   ... and the type of its min-SAD plane
+    hipEvent_t back_done = nullptr;                          // recorded at the end of a BACK phase: the next FRONT phase (possibly on another stream) waits for it
+    bool back_done_valid = false;
     std::unordered_map<int, Slot> slots;
     GipStereoModel model;
     gip_bm_params params{};
@@ -411,6 +413,7 @@ int gip_destroy(gip_handle h)
         if (e) (void)hipEventDestroy(e);
     if (h->match_fork) (void)hipEventDestroy(h->match_fork);
     if (h->match_join) (void)hipEventDestroy(h->match_join);
+    if (h->back_done) (void)hipEventDestroy(h->back_done);
     if (h->l_strm) (void)hipStreamDestroy(h->l_strm);
     if (h->r_strm) (void)hipStreamDestroy(h->r_strm);
     delete h;
@@ -1256,6 +1259,9 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
         h->tev.push_back(e);
     }
     hipEvent_t* ev = &h->tev[5 * h->timing_runs];
+    // FRONT and BACK may run on different streams (all FRONT phases in order on one, all BACK phases on another: neither chain then waits for the
+    // other): the buffers of this handle are free for the next FRONT only when the previous BACK is through with them
+    if (phase == GIP_BATCH_FRONT && h->back_done_valid) H_HIP(h, hipStreamWaitEvent(st, h->back_done, 0));
     if (front) H_HIP(h, hipEventRecord(ev[2], st));
     // stage 1: colour (StereoProcessor.cpp:183-217)
     const uint8_t* mono[2] = {d->left_raw, d->right_raw};
@@ -1382,6 +1388,11 @@ int gip_batch_run(gip_handle h, const gip_batch_desc* d, gip_stream stream)
                                           rect_color_cn == 1 ? rplane : npx * 3, st, tab, bp.num_disparities, true), "disparity outputs");
     }
     H_HIP(h, hipEventRecord(ev[3], st));
+    if (phase == GIP_BATCH_BACK) {
+        if (!h->back_done) H_HIP(h, hipEventCreateWithFlags(&h->back_done, hipEventDisableTiming));
+        H_HIP(h, hipEventRecord(h->back_done, st));
+        h->back_done_valid = true;
+    }
     h->timing_runs++;
 #undef B_STEP
     return GIP_OK;

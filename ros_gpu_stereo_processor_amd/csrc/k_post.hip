@@ -435,15 +435,19 @@ __global__ void __launch_bounds__(64) k_spk_scan4(const int16_t* __restrict__ di
     int n_run = 0, n_join = 0, carry_start = 0;
     int pv = new_val, pb = new_val;                 // last pixel of the previous step (rows y and y+1)
     uint2 nV = load4(d0, 4 * lane, true), nB = load4(d1, 4 * lane, has_next);
+    // the first pixel of the NEXT step (lane 63's right neighbour) is loaded a step earlier still, by itself: read out of nV it would make this
+    // step wait for the loads it has only just issued, and the prefetch would be none
+    int nF = 256 < w ? (int)d0[256] : new_val;
     for (int c0 = 0; c0 < w; c0 += 256) {
         const int x0 = c0 + 4 * lane;
         const uint2 V = nV, B = nB;
+        const int nfirst = nF;
         nV = load4(d0, x0 + 256, c0 + 256 < w);
         nB = load4(d1, x0 + 256, has_next && c0 + 256 < w);
+        nF = c0 + 512 < w ? (int)d0[c0 + 512] : new_val;
         int v[4] = {(short)(V.x & 0xFFFFu), (short)(V.x >> 16), (short)(V.y & 0xFFFFu), (short)(V.y >> 16)};
         int b[4] = {(short)(B.x & 0xFFFFu), (short)(B.x >> 16), (short)(B.y & 0xFFFFu), (short)(B.y >> 16)};
         int vl = __shfl_up(v[3], 1), bl = __shfl_up(b[3], 1), vr = __shfl_down(v[0], 1);
-        const int nfirst = (short)((u32)__shfl((int)nV.x, 0) & 0xFFFFu);
         if (lane == 0) { vl = pv; bl = pb; }
         if (lane == 63) vr = nfirst;
         pv = __shfl(v[3], 63);

@@ -194,6 +194,22 @@ def test_concurrent_stream_set_and_front_back_phases(gpu):
         assert torch.equal(p.disparity, alone[k][0]), k
         assert torch.equal(p.disparity_f32, alone[k][1]), k
         assert torch.equal(p.pointcloud.view(torch.int32), alone[k][2].view(torch.int32)), k
+    # FRONT phases in order on one stream, BACK phases on another, matchers on the third: the handle orders its own buffers by events
+    for p in pipes:
+        p.disparity.zero_(); p.disparity_f32.zero_(); p.pointcloud.zero_()
+    torch.cuda.synchronize()
+    sf, sb, sm3 = [torch.cuda.ExternalStream(hd, device=gpu) for hd in handles[:3]]
+    for i in range(9):
+        with torch.cuda.stream(sf):
+            pipes[i % 2].run(*ins[i % 2], sm3, phase=capi.BATCH_FRONT)
+        with torch.cuda.stream(sb):
+            pipes[i % 2].run(*ins[i % 2], sm3, phase=capi.BATCH_BACK)
+    torch.cuda.synchronize()
+    for k, p in enumerate(pipes):
+        assert torch.equal(p.disparity, alone[k][0]), k
+        assert torch.equal(p.disparity_f32, alone[k][1]), k
+        assert torch.equal(p.pointcloud.view(torch.int32), alone[k][2].view(torch.int32)), k
+    del sf, sb, sm3
     # phases on the caller's own stream (no matcher stream): FRONT then BACK is the whole chain
     pipes[0].disparity.zero_()
     pipes[0].run(*ins[0], phase=capi.BATCH_FRONT)
