@@ -598,28 +598,35 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
         csw[q] = (live_lane ? cs + (size_t)(q * NLIVE + t - TLO) * CSPB : dump + 4 * doff) + (size_t)(4 * NG * s) * 2;
     });
 
-    // The results of a row are STORED one iteration later, right before the next row's loads are issued: the s_waitcnt vmcnt(0) in front of
-    // commit() (the prefetched row is needed there) then finds loads and stores that are a whole row old, instead of stores issued a few hundred
-    // cycles earlier whose acknowledgement it would have to sit out (gfx9 counts loads and stores in the one vmcnt).
+    // Big one-wave kernels (NG >= 7: two waves per SIMD whatever they do, registers to spare) STORE the results of a row one iteration later,
+    // right before the next row's loads are issued: the s_waitcnt vmcnt(0) in front of commit() then finds loads and stores that are a whole row
+    // old instead of stores issued a few hundred cycles earlier (gfx9 counts loads and stores in the one vmcnt): +0.8 % pairs/s at the metric's
+    // shape.  Everywhere else the five registers per pixel cost more than they buy -- the pair kernels (two pixels per lane) fall from three to
+    // two waves per SIMD with them, -7 % alone at ndisp 48 / block 19.
+    constexpr bool DEFER = NW == 1 && NSUB == 1 && NG >= 7;
     bool pend_w[NFIN];
     int pend_d[NFIN], pend_ms[NFIN];
 #pragma unroll
     for (int jf = 0; jf < NFIN; jf++) { pend_w[jf] = false; pend_d[jf] = 0; pend_ms[jf] = 0; }
-    auto flush_row = [&](int yr) {
-#pragma unroll
-        for (int jf = 0; jf < NFIN; jf++) {
-            if (!pend_w[jf]) continue;
-            const int c_out = c0 + 4 * t + qf0 + jf;
-            disp[(size_t)yr * a.dpitch + a.lofs + c_out] = (int16_t)pend_d[jf];
-            if (cost) {
-                if (a.cost16) ((uint16_t*)cost)[(size_t)yr * a.cpitch + a.lofs + c_out] = (uint16_t)pend_ms[jf];
-                else cost[(size_t)yr * a.cpitch + a.lofs + c_out] = pend_ms[jf];
-            }
-            pend_w[jf] = false;
+    auto store_px = [&](int yr, int jf, int d_out, int minsad) {
+        const int c_out = c0 + 4 * t + qf0 + jf;
+        disp[(size_t)yr * a.dpitch + a.lofs + c_out] = (int16_t)d_out;
+        if (cost) {
+            if (a.cost16) ((uint16_t*)cost)[(size_t)yr * a.cpitch + a.lofs + c_out] = (uint16_t)minsad;
+            else cost[(size_t)yr * a.cpitch + a.lofs + c_out] = minsad;
         }
     };
-    // One iteration (row y): commit row y+R to the ring -> issue its LDS reads (A), the stores of row y-1 and the global loads of row y+R+1 ->
-    // add row y+R -> window sums / WTA / parks -> merge, uniqueness, finalise -> subtract row y-R (the row that leaves the window).
+    auto flush_row = [&](int yr) {
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int jf = 0; jf < NFIN; jf++) {
+                if (pend_w[jf]) store_px(yr, jf, pend_d[jf], pend_ms[jf]);
+                pend_w[jf] = false;
+            }
+        }
+    };
+    // One iteration (row y): commit row y+R to the ring -> issue its LDS reads (A), (DEFER) the stores of row y-1 and the global loads of row
+    // y+R+1 -> add row y+R -> window sums / WTA / parks -> merge, uniqueness, finalise, store -> subtract row y-R (the row that leaves the window).
     for (int y = ya; y < yb; y++) {
         wg_sync();                // every wave is done with the slot row y+R replaces
         commit(y + R);
@@ -844,9 +851,13 @@ __device__ __forceinline__ void bm_c4_tile(const BmArgs& a, uint8_t* smem_raw, i
                 if (ok) d_out = v >> 4;
             }
         }
-        pend_w[jf] = writer;
-        pend_d[jf] = d_out;
-        pend_ms[jf] = minsad;
+        if constexpr (DEFER) {
+            pend_w[jf] = writer;
+            pend_d[jf] = d_out;
+            pend_ms[jf] = minsad;
+        } else {
+            if (writer) store_px(y, jf, d_out, minsad);
+        }
         }   // the lane's pixels
         }   // finalising wave
         if (!(C4_ABLATE & 1)) sub_regs(RF ? read_slot(1) : read_row(y - R));
