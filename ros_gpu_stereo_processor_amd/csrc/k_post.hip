@@ -175,7 +175,8 @@ __global__ void k_disp_to_f32(const int16_t* __restrict__ disp, size_t dpitch, f
 //                segment between a run of row y and a run of row y+1 -- appended to a compact per-row list
 //   k_spk_strip  one workgroup per strip of SPK_STRIP rows: union-find over the strip's runs in LDS, component sizes
 //                accumulated at the strip-local roots; writes parent (= local root) and size (at local roots, else 0)
-//   k_spk_cross  one wavefront per strip boundary row: global atomicMin union-find over the joins that cross strips
+//   k_spk_cross  one workgroup per strip: global atomicMin union-find over the joins that cross the strip's lower seam (and, for a strip
+//                too dense for the LDS level, over the joins of its interior rows)
 //   k_spk_sizes  strip-local roots that lost their root status add their size to the global root (+ path compression)
 //   k_spk_apply  one wavefront per row: runs whose component has <= maxSpeckleSize pixels are overwritten with newVal
 // Why: only ~1 % of the pixels start a union or close a run, but each of those is a chain of dependent memory round trips.
@@ -585,26 +586,32 @@ __global__ void __launch_bounds__(SPK_TPB) k_spk_strip(SpkScratch S, int w, int 
 }
 
 constexpr int SPK_CROSS_TPB = 256;     // four waves per boundary row: a row of a 4096-wide map has hundreds of joins, each a chain of dependent accesses
+// One workgroup per STRIP: the joins across the strip's lower seam (last row of the strip -> first row of the next), and -- only when the strip was
+// too dense for the LDS level (global_strip) -- the joins of its interior rows as well.  (One workgroup per image row, seven of eight of which
+// found nothing to do, was 95 744 waves per 64 KITTI-size maps for 11 968 rows with work.)
 __global__ void __launch_bounds__(SPK_CROSS_TPB) k_spk_cross(SpkScratch S, int w, int h, int nstrips)
 {
-    const int y = blockIdx.x;                       // joins between rows y and y+1
-    if (((y + 1) % SPK_STRIP) != 0 && !S.global_strip[blockIdx.z * (size_t)nstrips + y / SPK_STRIP]) return;
+    const int strip = blockIdx.x;
+    const bool all_rows = S.global_strip[blockIdx.z * (size_t)nstrips + strip] != 0;
     const size_t ibase = blockIdx.z * (size_t)w * h;
-    const size_t rb = ibase + (size_t)y * w;
-    const int n = S.njoin[blockIdx.z * (size_t)h + y];
     int* nd = S.parent + ibase;
-    for (int k0 = 0; k0 < n; k0 += SPK_CROSS_TPB) {
-        const int k = k0 + (int)threadIdx.x;
-        int a = 0, b = 0;
-        if (k < n) {
-            const u32 item = S.joinlist[rb + k];
-            const int x = (int)(item >> 16);
-            // the strip-local roots of the two runs (or, concurrently relinked, an ancestor: all a union needs); neighbouring joins mostly
-            // connect the same two large components: one union per run of equal pairs
-            a = __hip_atomic_load(&nd[y * w + (int)(item & 0xFFFFu)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b = __hip_atomic_load(&nd[(y + 1) * w + (int)S.ord16[rb + w + x]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ylast = (strip + 1) * SPK_STRIP - 1;                          // joins between rows y and y+1
+    for (int y = all_rows ? strip * SPK_STRIP : ylast; y <= ylast && y < h - 1; y++) {
+        const size_t rb = ibase + (size_t)y * w;
+        const int n = S.njoin[blockIdx.z * (size_t)h + y];
+        for (int k0 = 0; k0 < n; k0 += SPK_CROSS_TPB) {
+            const int k = k0 + (int)threadIdx.x;
+            int a = 0, b = 0;
+            if (k < n) {
+                const u32 item = S.joinlist[rb + k];
+                const int x = (int)(item >> 16);
+                // the strip-local roots of the two runs (or, concurrently relinked, an ancestor: all a union needs); neighbouring joins mostly
+                // connect the same two large components: one union per run of equal pairs
+                a = __hip_atomic_load(&nd[y * w + (int)(item & 0xFFFFu)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b = __hip_atomic_load(&nd[(y + 1) * w + (int)S.ord16[rb + w + x]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (first_of_key_run(k < n, ((u64)(u32)a << 32) | (u64)(u32)b)) uf_union(nd, a, b);
         }
-        if (first_of_key_run(k < n, ((u64)(u32)a << 32) | (u64)(u32)b)) uf_union(nd, a, b);
     }
 }
 
@@ -1114,7 +1121,7 @@ int gipk_speckle_label(const int16_t* disp, size_t disp_pitch, int w, int h, int
     else if (pairs_ok) hipLaunchKernelGGL(k_spk_scan2, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     else hipLaunchKernelGGL(k_spk_scan, dim3(h, 1, batch), dim3(64), 0, st, disp, disp_pitch / 2, S, w, h, new_val, max_diff, disp_bstride);
     hipLaunchKernelGGL(k_spk_strip, dim3(nstrips, 1, batch), dim3(SPK_TPB), (size_t)SPK_CAP * 8, st, S, w, h, nstrips);
-    if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(h - 1, 1, batch), dim3(SPK_CROSS_TPB), 0, st, S, w, h, nstrips);
+    if (h > 1) hipLaunchKernelGGL(k_spk_cross, dim3(nstrips, 1, batch), dim3(SPK_CROSS_TPB), 0, st, S, w, h, nstrips);
     hipLaunchKernelGGL(k_spk_sizes, dim3(h, 1, batch), dim3(64), 0, st, S, w, h);
     GIP_LAUNCH_CHECK();
     return GIP_OK;
