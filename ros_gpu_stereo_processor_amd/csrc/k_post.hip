@@ -106,11 +106,12 @@ __global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpi
         const int minD = mindisp, maxD = mindisp + ndisp;
         const int minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (minD < 0 ? minD : 0);
         const int maxdiff = disp12 * 16;
+        // (loaded whether or not the pixel is valid: a load that depended on d[i] would be a second memory round trip behind the first)
         u32 c[NI];
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             const int x = t + TPB * i;
-            c[i] = (x >= minX1 && x < maxX1 && d[i] != INVALID) ? (u32)cptr[x] : 0u;
+            c[i] = (x >= minX1 && x < maxX1 && x < w) ? (u32)cptr[x] : 0u;
         }
         for (int x = t; x < w; x += TPB) keys[x] = ~0ull;
         __syncthreads();
