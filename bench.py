@@ -33,11 +33,12 @@ WORKLOADS = {
     "kitti": dict(W=1242, H=375, NDISP=128, BLOCK=9, ENCODING="mono8", batch=256, depth=3, shared=True, kernel="k_bm_c4<8,4,1>",
                   name="KITTI-size 1242x375 mono8, ndisp=128 block=9, full chain rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)"
                        "->speckle(800,5)->f32 disparity+PointCloud2"),
-    "hd1080": dict(W=1920, H=1080, NDISP=256, BLOCK=21, ENCODING="bayer_rggb8", batch=8, depth=2, shared=False, kernel="k_bm_c4<4,10,4>",
+    "hd1080": dict(W=1920, H=1080, NDISP=256, BLOCK=21, ENCODING="bayer_rggb8", batch=8, depth=3, shared=False, kernel="k_bm_c4<4,10,4>",
                    name="1920x1080 bayer_rggb8, ndisp=256 block=21, full chain debayer(gray L/R + colour L)->rectify->StereoBM(XSOBEL,tex10,uniq15,"
                         "L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
-    # (two frames in flight with their matchers on ONE shared stream: 1.61 k frames/s against 1.45 k with a matcher stream per frame)
-    "uhd4k": dict(W=4096, H=2160, NDISP=192, BLOCK=15, ENCODING="mono8", batch=1, depth=2, shared=True, kernel="k_bm_c4<6,7,2>",
+    # (three frames in flight, each with its matcher on its own stream: 1.84 k frames/s; two frames with a shared matcher stream 1.56 k, with their
+    # own 1.65 k -- since the L/R check of rows wider than 1536 pixels keeps its keys in 4 bytes per column and fits next to the matcher)
+    "uhd4k": dict(W=4096, H=2160, NDISP=192, BLOCK=15, ENCODING="mono8", batch=1, depth=3, shared=False, kernel="k_bm_c4<6,7,2>",
                   name="4096x2160 mono8, ndisp=192 block=15, ONE frame per step on one GPU (BASELINE configs[4] without the row split), full chain "
                        "rectify->StereoBM(XSOBEL,tex10,uniq15,L/R disp12=1)->speckle(800,5)->f32 disparity+PointCloud2"),
     # BASELINE configs[0]'s size and matcher shape (the reference's own CPU-runnable case) on the GPU path
@@ -308,7 +309,7 @@ def rowsplit_native(args, wl):
             dev_frames[d] = ([torch.from_numpy(x).to("cuda:%d" % d) for x in lraw], [torch.from_numpy(x).to("cuda:%d" % d) for x in rraw])
         return dev_frames[d]
 
-    def measure(nt, depth=2, halo_mode=None, gather_mode=0):
+    def measure(nt, depth=3, halo_mode=None, gather_mode=0):       # (three frames in flight: 0.54 ms per frame on one device, two: 0.60, four: 0.62)
         halo_mode = args.halo_mode if halo_mode is None else halo_mode
         devices = [t % ndev for t in range(nt)]
         groups = [RS.RowSplit(W, H, calib, params, nt, ENCODING, outputs, SPECKLE_SIZE, SPECKLE_DIFF, devices=devices, halo_mode=halo_mode, host_threads=args.host_threads,

@@ -78,13 +78,20 @@ __global__ void k_bm_finalize(int16_t* disp, size_t dpitch, const CT* cost, size
 
 // Same, for rows of at most 256 * NI pixels: every thread keeps its NI pixels in registers across the three phases, so the
 // disparity row is read once and only the pixels that change are written back.
-template <int NI, class CT>
+// K32 (uint16 costs of the column-sum matcher, ndisp <= 256; used for rows wider than 1536 pixels): the key is ONE dword, cost << 12 | (d - minD * 16).
+// For a fixed target column the candidates' source columns x = x2 + ((d + 8) >> 4) are ordered like their disparities, so "smallest d" breaks cost
+// ties exactly as "smallest x" does, and d is all the second pass reads back.  Half the LDS: a 4096-pixel row needs 16 KB instead of 32 KB, which is
+// the difference between fitting next to a CU's matcher workgroups and waiting for one of them to leave (the L/R check of a 4096x2160 frame took
+// 296 us next to the following frame's matcher, 60 us alone).  For narrow rows the 64-bit form stays: there the smaller footprint lets MORE of these
+// workgroups in next to the matcher and the pipelined step gets slower.
+template <int NI, class CT, bool K32>
 __global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpitch, const CT* cost, size_t cpitch, int w, int h, int mindisp,
                                                         int ndisp, int disp12, int roi_x, int roi_y, int roi_w, int roi_h, int wr0, int wr1, size_t dbs,
                                                         size_t cbs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     u64* keys = (u64*)smem_raw;
+    u32* keys32 = (u32*)smem_raw;
     const int y = blockIdx.x, t = threadIdx.x;
     int16_t* dptr = (int16_t*)((uint8_t*)disp + blockIdx.z * dbs) + (size_t)y * dpitch;
     const int INVALID = (mindisp - 1) * 16;
@@ -113,7 +120,9 @@ __global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpi
             const int x = t + TPB * i;
             c[i] = (x >= minX1 && x < maxX1 && x < w) ? (u32)cptr[x] : 0u;
         }
-        for (int x = t; x < w; x += TPB) keys[x] = ~0ull;
+        const int d_lo = mindisp * 16;
+        if (K32) for (int x = t; x < w; x += TPB) keys32[x] = ~0u;
+        else for (int x = t; x < w; x += TPB) keys[x] = ~0ull;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NI; i++) {
@@ -121,7 +130,8 @@ __global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpi
             if (x < minX1 || x >= maxX1 || d[i] == INVALID) continue;
             const int x2 = x - ((d[i] + 8) >> 4);
             if (x2 < 0 || x2 >= w) continue;
-            atomicMin(&keys[x2], ((u64)c[i] << 32) | ((u64)(u32)x << 16) | (u64)(unsigned short)d[i]);
+            if (K32) atomicMin(&keys32[x2], (c[i] << 12) | ((u32)(d[i] - d_lo) & 0xFFFu));
+            else atomicMin(&keys[x2], ((u64)c[i] << 32) | ((u64)(u32)x << 16) | (u64)(unsigned short)d[i]);
         }
         __syncthreads();
 #pragma unroll
@@ -130,13 +140,24 @@ __global__ void __launch_bounds__(TPB) k_bm_finalize_r(int16_t* disp, size_t dpi
             if (x < minX1 || x >= maxX1 || d[i] == INVALID) continue;
             const int x0 = x - (d[i] >> 4), x1 = x - ((d[i] + 15) >> 4);
             bool bad0 = false, bad1 = false;
-            if (x0 >= 0 && x0 < w) {
-                const u64 k = keys[x0];
-                if (k != ~0ull) { const int df = (int)(short)(unsigned short)(k & 0xFFFFu) - d[i]; bad0 = (df < 0 ? -df : df) > maxdiff; }
-            }
-            if (x1 >= 0 && x1 < w) {
-                const u64 k = keys[x1];
-                if (k != ~0ull) { const int df = (int)(short)(unsigned short)(k & 0xFFFFu) - d[i]; bad1 = (df < 0 ? -df : df) > maxdiff; }
+            if (K32) {
+                if (x0 >= 0 && x0 < w) {
+                    const u32 k = keys32[x0];
+                    if (k != ~0u) { const int df = (int)(k & 0xFFFu) + d_lo - d[i]; bad0 = (df < 0 ? -df : df) > maxdiff; }
+                }
+                if (x1 >= 0 && x1 < w) {
+                    const u32 k = keys32[x1];
+                    if (k != ~0u) { const int df = (int)(k & 0xFFFu) + d_lo - d[i]; bad1 = (df < 0 ? -df : df) > maxdiff; }
+                }
+            } else {
+                if (x0 >= 0 && x0 < w) {
+                    const u64 k = keys[x0];
+                    if (k != ~0ull) { const int df = (int)(short)(unsigned short)(k & 0xFFFFu) - d[i]; bad0 = (df < 0 ? -df : df) > maxdiff; }
+                }
+                if (x1 >= 0 && x1 < w) {
+                    const u64 k = keys[x1];
+                    if (k != ~0ull) { const int df = (int)(short)(unsigned short)(k & 0xFFFFu) - d[i]; bad1 = (df < 0 ? -df : df) > maxdiff; }
+                }
             }
             kill[i] = bad0 && bad1;
         }
@@ -1057,11 +1078,23 @@ static int finalize_launch(int16_t* disp, size_t disp_pitch, const CT* cost, siz
 #define GIP_FINALIZE_ARGS disp, disp_pitch / 2, cost, cost ? cost_pitch / sizeof(CT) : 0, w, h, p->min_disparity, p->num_disparities, g.degenerate ? -1 : p->disp12_max_diff, rx, ry, \
                           rw, rh, g.lofs, g.lofs + g.width1, disp_bstride, cost_bstride
     const dim3 grid(h, 1, batch);
-    if (w <= 2 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<2, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
-    else if (w <= 5 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<5, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
-    else if (w <= 8 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<8, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
-    else if (w <= 16 * TPB) hipLaunchKernelGGL((k_bm_finalize_r<16, CT>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+    // one-dword keys for wide rows (where the cost is a uint16 and d - minD * 16 fits 12 bits)
+#ifndef K32_MIN_W
+#define K32_MIN_W 1536     /* measured: 1242-wide rows lose with the one-dword form, 1920-wide gain 1 %, 4096-wide 13 % */
+#endif
+    const bool k32 = sizeof(CT) == 2 && p->num_disparities <= 256 && p->disp12_max_diff >= 0 && w > K32_MIN_W;
+    const size_t sh32 = (size_t)w * 4;
+#define GIP_FINALIZE_R(NI)                                                                                                                       \
+    do {                                                                                                                                         \
+        if (k32) hipLaunchKernelGGL((k_bm_finalize_r<NI, CT, sizeof(CT) == 2>), grid, dim3(TPB), sh32, (hipStream_t)stream, GIP_FINALIZE_ARGS);  \
+        else hipLaunchKernelGGL((k_bm_finalize_r<NI, CT, false>), grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);                   \
+    } while (0)
+    if (w <= 2 * TPB) GIP_FINALIZE_R(2);
+    else if (w <= 5 * TPB) GIP_FINALIZE_R(5);
+    else if (w <= 8 * TPB) GIP_FINALIZE_R(8);
+    else if (w <= 16 * TPB) GIP_FINALIZE_R(16);
     else hipLaunchKernelGGL(k_bm_finalize<CT>, grid, dim3(TPB), sh, (hipStream_t)stream, GIP_FINALIZE_ARGS);
+#undef GIP_FINALIZE_R
 #undef GIP_FINALIZE_ARGS
     GIP_LAUNCH_CHECK();
     return GIP_OK;

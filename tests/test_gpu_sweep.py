@@ -63,3 +63,27 @@ def test_both_row_staging_forms_agree_for_every_disparity_count(gpu, block):
         assert torch.equal(pipe.disparity, own), (nd, block)
         assert (own != -16).float().mean() > 0.02, (nd, block)
         pipe.close()
+
+
+@pytest.mark.parametrize("w,nd,mind", [(1537, 64, 0), (1700, 256, -8), (2049, 128, 5), (3000, 48, 0), (4096, 192, 0)])
+def test_lr_check_with_one_dword_keys_on_wide_rows(gpu, oracle, w, nd, mind):
+    """Rows wider than 1536 pixels run the L/R check (cv::validateDisparity) with 32-bit keys cost << 12 | (d - 16 minD) instead of the 64-bit
+    (cost, x, d) keys (k_bm_finalize_r, k_post.hip): same winners, same ties.  Whole matcher + check against the oracle, batches of 1 and 8."""
+    import torch
+    from ros_gpu_stereo_processor_amd import kernels as K
+    O = oracle
+    h, block = 45, 11
+    kw = dict(prefilter_type=1, prefilter_size=9, prefilter_cap=31, block_size=block, min_disparity=mind, num_disparities=nd, texture_threshold=10,
+              uniqueness_ratio=15, disp12_max_diff=1, speckle_window_size=0, speckle_range=0)
+    pairs = [synth.rectified_pair(w, h, nd, seed=9000 + w + i)[:2] for i in range(2)]
+    for B in (1, 8):
+        l = np.stack([pairs[i % 2][0] for i in range(B)])
+        r = np.stack([pairs[i % 2][1] for i in range(B)])
+        got = K.stereobm(torch.from_numpy(l).to(gpu), torch.from_numpy(r).to(gpu), K.bm_params(**kw)).cpu().numpy()
+        for i in range(min(B, 2)):
+            exp = O.stereobm(l[i], r[i], O.bm_params(**kw))
+            assert np.array_equal(got[i], exp), (w, nd, mind, B, i, int((got[i] != exp).sum()))
+            # the check must have something to do: the same map without it differs
+        kw2 = dict(kw, disp12_max_diff=-1)
+        no_lr = K.stereobm(torch.from_numpy(l[:1]).to(gpu), torch.from_numpy(r[:1]).to(gpu), K.bm_params(**kw2)).cpu().numpy()
+        assert (no_lr[0] != got[0]).sum() > 0, "the L/R check rejected nothing: the test does not exercise it"
