@@ -173,3 +173,34 @@ def test_streamer_failed_launch_is_sticky_and_shapes_are_checked(gpu):
     assert st.delivered() == 1
     st.close()
     proc.close()
+
+
+def test_streamer_camera_rate_gets_batches_of_one_and_a_burst_gets_full_batches(gpu):
+    """Adaptive batching: a caller that submits slowly (a camera) finds the compute lane free and the copy-out idle every time -- every pair is
+    launched by itself and delivered without waiting for a batch to fill or for a flush; a caller that submits as fast as it can gets batches that
+    fill up (far fewer launches than pairs)."""
+    import time
+    from ros_gpu_stereo_processor_amd import capi
+    from ros_gpu_stereo_processor_amd.streamer import Streamer
+    w, h, nd = 640, 240, 64
+    proc, calib = _processor(w, h, nd, 7)
+    l, r = synth.raw_pair(w, h, nd, seed=5, calib=calib)[:2]
+    st = Streamer(proc, w, h, "mono8", capi.TOPIC_DISPARITY, frames_per_batch=16)
+    for i in range(12):
+        st.submit(l, r)
+        deadline = time.time() + 2.0
+        while st.delivered() < i + 1 and time.time() < deadline:      # delivered WITHOUT flush: nothing waits for a batch to fill
+            time.sleep(0.0005)
+        assert st.delivered() == i + 1, "pair %d was not delivered on its own" % i
+        time.sleep(0.003)
+    assert st.launches() == 12
+    # a burst: the lane / the copy-out are busy most of the time, the batches fill
+    n = 16 * 20
+    l0 = st.launches()
+    for _ in range(n):
+        st.submit(l, r)
+    st.flush()
+    assert st.delivered() == 12 + n
+    assert st.launches() - l0 <= n // 3, (st.launches() - l0, n)
+    st.close()
+    proc.close()
