@@ -32,7 +32,7 @@ def test_cpp_mirror_classes(gpu, oracle, kitchen, calib, calib_files, tmp_path):
     gb = subprocess.run([str(build / "gip_bench"), "--batch", "4", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=300)
     assert gb.returncode == 0, gb.stdout + gb.stderr
     line = json.loads(gb.stdout.strip().splitlines()[-1])
-    assert line["value"] > 0 and line["pairs_per_step"] == 4 and line["independent_streams"] >= 3 and line["valid_fraction_first_image"] > 0.1
+    assert line["value"] > 0 and line["pairs_per_step"] == 4 and line["independent_streams"] >= 2 and line["valid_fraction_first_image"] > 0.1
     run(cmake, "-S", os.path.join(ROOT, "tests", "cpp", "consumer"), "-B", str(cbuild), "-DCMAKE_PREFIX_PATH=%s;/opt/rocm" % prefix)
     run(cmake, "--build", str(cbuild), "-j", jobs)
     exe = cbuild / "test_processor"

@@ -154,7 +154,7 @@ def test_concurrent_stream_set_and_front_back_phases(gpu):
     assert lib.gip_concurrent_streams_create(0, 2, None, None) == 1 and lib.gip_concurrent_streams_create(99, 2, arr, None) == 5
     idle = [torch.cuda.Stream(device=gpu) for _ in range(3)]      # streams created before must not matter
     handles, independent = capi.concurrent_streams(4, 0)
-    assert len(set(handles)) == 4 and all(handles) and 3 <= independent <= 4
+    assert len(set(handles)) == 4 and all(handles) and 2 <= independent <= 4      # (4 with the default four hardware queues on an idle device)
     handles6, independent6 = capi.concurrent_streams(6, 0)        # more than the hardware queues: still six usable streams
     assert len(set(handles6)) == 6 and 1 <= independent6 <= 6
     capi.release_streams(handles6, 0)
