@@ -755,10 +755,10 @@ def chain_workload(args, key, wl, ctx, steps, warmup, batch, depth, probes):
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                if tj.get("batch") == B and tj.get("workload") == "1242x375_nd128_b9" and key == "kitti":
+                tj = json.load(open(tpath)).get("workloads", {}).get(key)
+                if tj and tj.get("batch") == B:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = "static: profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this command, not measured in this run)"
+                    traffic_source = "static: profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this workload, not measured in this run)"
             except Exception:
                 traffic = None
         # the timed configuration checked against the oracle (outside the timing): frame 0 of the LAST step every pipeline ran, the whole chain

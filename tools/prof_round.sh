@@ -24,7 +24,8 @@ kitti)
   pmc r03_pmc_sq_all_kernels "" SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVES -- ;;
 hd1080|uhd4k|euroc|refdefault)
   ks r03_$what --workload $what ; ks r03_${what}_depth1 --workload $what --depth 1 --steps 10 --warmup 2
-  pmc r03_${what}_pmc_sq1_k_bm_c4 k_bm_c4 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -- --workload $what ;;
+  pmc r03_${what}_pmc_sq1_k_bm_c4 k_bm_c4 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -- --workload $what
+  pmc r03_${what}_pmc_fetch_size k_bm_c4 FETCH_SIZE -- --workload $what ; pmc r03_${what}_pmc_write_size k_bm_c4 WRITE_SIZE -- --workload $what ;;
 rowsplit)
   rm -rf /tmp/p_rs; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/p_rs -o rs4 -- python3 $R/tools/rowsplit_probe.py 4 20 serial > $O/r03_rowsplit4_serial.txt 2>&1
   python3 $R/tools/rocpd_stats.py $(find /tmp/p_rs -name "*results.db" | head -1) 30 > $O/r03_rowsplit4_kernel_stats.txt

@@ -21,6 +21,9 @@ for wl in ["", "hd1080_", "uhd4k_", "euroc_", "refdefault_"]:
         copy(f"{TAG}_{wl}{d1}kernel_stats.csv", f"{TAG}_{wl}{d1}kernel_stats.csv")
         copy(f"{TAG}_{wl}{d1}bench.json", f"{TAG}_{wl}{d1}bench_under_rocprof.json")
     copy(f"{TAG}_{wl}pmc_sq1_k_bm_c4.txt", f"{TAG}_{wl}pmc_sq1_k_bm_c4.txt")
+    if wl:
+        copy(f"{TAG}_{wl}pmc_fetch_size.txt", f"{TAG}_{wl}pmc_fetch_size.txt")
+        copy(f"{TAG}_{wl}pmc_write_size.txt", f"{TAG}_{wl}pmc_write_size.txt")
 for f in ["pmc_sq2_k_bm_c4", "pmc_sq_all_kernels", "pmc_fetch_size", "pmc_write_size", "rowsplit4_kernel_stats", "rowsplit4_serial"]:
     copy(f"{TAG}_{f}.txt", f"{TAG}_{f}.txt")
 copy(f"{TAG}_rowsplit_bench.json", f"{TAG}_rowsplit_bench.json")
@@ -39,20 +42,25 @@ def counter_of(path, kernel, counter):
     return None
 
 
-bench = json.loads(open(os.path.join(DST, f"{TAG}_bench_under_rocprof.json")).read().strip().splitlines()[-1])
-kern = bench["roofline"]["kernel"]
-kname = kern.split("<")[0]
-fetch_kb = counter_of(os.path.join(DST, f"{TAG}_pmc_fetch_size.txt"), kname, "FETCH_SIZE")
-write_kb = counter_of(os.path.join(DST, f"{TAG}_pmc_write_size.txt"), kname, "WRITE_SIZE")
-if fetch_kb is not None and write_kb is not None:
-    traffic = {"workload": "1242x375_nd128_b9", "batch": bench["config"]["pairs_per_step_per_gpu"], "kernel": kern,
-               "fetch_size_counter_bytes": fetch_kb * 1024.0, "write_size_bytes": write_kb * 1024.0, "fetch_correction": 2.0,
-               "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
-               "note": "rocprofv3 FETCH_SIZE reads exactly half of the streamed bytes on gfx950 at every access width (profiles/r02_pmc_calibration.txt: "
-                       "1 GiB copy kernels, 1/2/4/8/16 B per lane), WRITE_SIZE is exact; traffic = 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes "
-                       "(r03_pmc_fetch_size.txt, r03_pmc_write_size.txt)"}
-    json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
-    print("traffic.json: %.1f MB per launch" % (traffic["hbm_bytes_per_launch"] / 1e6))
+NOTE = ("rocprofv3 FETCH_SIZE reads exactly half of the streamed bytes on gfx950 at every access width (profiles/r02_pmc_calibration.txt: "
+        "1 GiB copy kernels, 1/2/4/8/16 B per lane), WRITE_SIZE is exact; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the dominant kernel, separate --pmc passes "
+        "(r03_[<workload>_]pmc_fetch_size.txt, r03_[<workload>_]pmc_write_size.txt)")
+traffic = {"note": NOTE, "workloads": {}}
+for key, wl in (("kitti", ""), ("hd1080", "hd1080_"), ("uhd4k", "uhd4k_"), ("euroc", "euroc_"), ("refdefault", "refdefault_")):
+    bpath = os.path.join(DST, f"{TAG}_{wl}bench_under_rocprof.json")
+    fpath, wpath = os.path.join(DST, f"{TAG}_{wl}pmc_fetch_size.txt"), os.path.join(DST, f"{TAG}_{wl}pmc_write_size.txt")
+    if not (os.path.exists(bpath) and os.path.exists(fpath) and os.path.exists(wpath)):
+        continue
+    bench = json.loads(open(bpath).read().strip().splitlines()[-1])
+    kern = bench["roofline"]["kernel"]
+    kname = kern.split("<")[0]
+    fetch_kb, write_kb = counter_of(fpath, kname, "FETCH_SIZE"), counter_of(wpath, kname, "WRITE_SIZE")
+    if fetch_kb is None or write_kb is None:
+        continue
+    traffic["workloads"][key] = {"batch": bench["config"]["pairs_per_step_per_gpu"], "kernel": kern, "fetch_size_counter_bytes": fetch_kb * 1024.0,
+                                 "write_size_bytes": write_kb * 1024.0, "fetch_correction": 2.0, "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0}
+    print("traffic.json: %s %.1f MB per launch" % (key, traffic["workloads"][key]["hbm_bytes_per_launch"] / 1e6))
+json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 
 
 def stats(path):
